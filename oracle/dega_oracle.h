@@ -1,0 +1,85 @@
+/* dega_oracle.h -- CPU restatement of the reference's DEGA hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker.  The product path (data-compressor_amd/) never links or calls it.
+ *
+ * Parity status: PINNED.  This restatement is checked (tests/test_oracle_golden.py) against
+ *   - the golden vectors generated from the compiled reference (tests/golden/, made by
+ *     tests/golden/make_golden.py from oracle/_ref), SURVEY.md Appendix B, and
+ *   - the compiled reference itself (oracle/_ref/libdcref.so, built from the sources where
+ *     they lie under /root/reference by oracle/Makefile) on random streams, in this container.
+ *
+ * Every stage works on an in-memory bit stream with an EXACT bit length, which is what the
+ * reference's DCCLI hands from stage to stage (DCCLI/src/cli.c:430-466, the write->read mode
+ * switch keeps the fractional byte: DCIOLib/src/bit_file_buffer.c:127-144).
+ * Bit order: MSB first inside a byte, n-bit values most significant bit first
+ * (DCIOLib/src/bit_file_buffer.c:220-248, 297-308).
+ */
+#ifndef DEGA_ORACLE_H
+#define DEGA_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error codes: same values as the reference's common/inc/err_codes.h:8-32 */
+#define ORC_NO_ERROR 0
+#define ORC_ERROR_INVALID_VALUE (-1)
+#define ORC_ERROR_INVALID_FORMAT (-3)
+#define ORC_ERROR_MEMORY (-6)
+#define ORC_ERROR_LIBRARY_CALL (-11)
+
+typedef struct orc_bits
+{
+  uint8_t *data;    /* zero-padded to a whole byte */
+  size_t nbits;     /* exact number of valid bits */
+  size_t cap_bytes; /* allocated bytes */
+} orc_bits_t;
+
+void orc_bits_init(orc_bits_t *b);
+void orc_bits_free(orc_bits_t *b);
+void orc_bits_clear(orc_bits_t *b);
+int orc_bits_assign(orc_bits_t *b, const uint8_t *bytes, size_t nbits);
+size_t orc_bits_nbytes(const orc_bits_t *b); /* bytes a file would hold: ceil(nbits/8), but 1 for an empty stream
+                                                 (DCIOLib/src/bit_file_buffer.c:310-320: the final flush always writes one byte) */
+
+/* Stage functions: consume all of `in`, append to `out` (which the caller has cleared).
+   Return ORC_NO_ERROR or a negative code, like the reference's enc_dec_function_t (DCLib/inc/enc_dec.h:11). */
+int orc_normalize_encode(const orc_bits_t *in, orc_bits_t *out, float factor, unsigned valuesize); /* normalize.c:9-27 */
+int orc_normalize_decode(const orc_bits_t *in, orc_bits_t *out, float factor, unsigned valuesize); /* normalize.c:29-41 */
+int orc_diff_encode(const orc_bits_t *in, orc_bits_t *out, unsigned valuesize);                    /* diff.c:9-23 */
+int orc_diff_decode(const orc_bits_t *in, orc_bits_t *out, unsigned valuesize);                    /* diff.c:25-37 */
+int orc_seg_encode(const orc_bits_t *in, orc_bits_t *out, unsigned valuesize);                     /* seg.c:31-43 */
+int orc_seg_decode(const orc_bits_t *in, orc_bits_t *out, unsigned valuesize);                     /* seg.c:82-94 */
+int orc_bac_encode(const orc_bits_t *in, orc_bits_t *out, int adaptive);                           /* bac.c:147-166 */
+int orc_bac_decode(const orc_bits_t *in, orc_bits_t *out, int adaptive);                           /* bac.c:244-263 */
+
+/* Whole-chain helpers on one channel held as native int32 (the chain "encode diff # encode seg # encode bac [adaptive]"
+   fed with the channel's samples as big-endian 32-bit values, and its inverse).
+   out must hold at least orc_dega_worst_case_bytes(T) bytes.  *out_nbits receives the exact stream length in bits. */
+size_t orc_dega_worst_case_bytes(size_t T);
+int orc_dega_encode_i32(const int32_t *x, size_t T, int adaptive, uint8_t *out, size_t out_cap, uint64_t *out_nbits);
+/* Decodes at most max_T samples; *out_T receives the number decoded. in_nbits is the exact bit length; pass the
+   zero-padded byte length * 8 to decode "from a file" (the phantom padding is swallowed as in the reference). */
+int orc_dega_decode_i32(const uint8_t *in, uint64_t in_nbits, int adaptive, int32_t *x, size_t max_T, size_t *out_T);
+
+/* Float entry: "encode normalize # encode diff # encode seg # encode bac" on raw native-endian float32 samples. */
+int orc_dega_encode_f32(const float *v, size_t T, float factor, int adaptive, uint8_t *out, size_t out_cap, uint64_t *out_nbits);
+int orc_dega_decode_f32(const uint8_t *in, uint64_t in_nbits, float factor, int adaptive, float *v, size_t max_T, size_t *out_T);
+
+/* Batch form used by the GPU parity tests and the CPU baseline: x is [T][ld] (time-major, channel c at column c),
+   channel c's stream is written at out + c*out_cap_per_ch, its exact bit length to out_bits[c], its status to err[c]. */
+int orc_dega_encode_batch_tc(const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive,
+                             uint8_t *out, size_t out_cap_per_ch, uint64_t *out_bits, int32_t *err);
+int orc_dega_decode_batch_tc(const uint8_t *in, size_t in_cap_per_ch, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                             int adaptive, int32_t *x_tc, int32_t *err);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in tests/golden/ from the COMPILED REFERENCE (oracle/_ref, built by oracle/Makefile
+from /root/reference).  Run in the build container only (the reference does not exist on the GPU box):
+
+    make -C oracle && python tests/golden/make_golden.py
+
+Fixtures are data only (inputs + the reference's outputs):
+  input.txt.gz         the reference's own test file DCCLI/testdata/input.txt (100 000 lines), gzip'ed
+  testfile.json        size / bit length / sha256 of every stage of the reference's `make test` chain on it
+                       (DCCLI/build/gcc/Makefile:75-77), plus first/last bytes
+  dega_adaptive.bin    the canonical DEGA stream of the test file (chained: decode csv # encode normalize #
+                       encode diff # encode seg # encode bac adaptive), as the file DCCLI writes
+  kats.json            known-answer vectors re-generated through the reference library
+  channels.npz         small int32 channel batches [T][C] + the reference's per-channel DEGA streams
+  floats.npz           float32 edge cases + the reference's normalize / denormalize results
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import orc  # noqa: E402
+
+REF_INPUT = "/root/reference/DataCompressor/DCCLI/testdata/input.txt"
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def dccli(infile, stages):
+    """Run the reference CLI; returns (file bytes, (bytes, bits) it reports having written)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "out.bin")
+        args = [orc.REF_CLI, infile, out]
+        for i, s in enumerate(stages):
+            if i:
+                args.append("#")
+            args += s.split()
+        p = subprocess.run(args, capture_output=True, text=True)
+        if p.returncode != 0:
+            return None, p.returncode
+        wrote = [ln for ln in p.stdout.splitlines() if "Wrote" in ln][-1]
+        nbytes = int(wrote.split("(")[1].split()[0])
+        nbits = int(wrote.split("and")[1].split()[0])
+        with open(out, "rb") as f:
+            return f.read(), (nbytes, nbits)
+
+
+def testfile():
+    with open(REF_INPUT, "rb") as f:
+        raw = f.read()
+    with gzip.GzipFile(os.path.join(HERE, "input.txt.gz"), "wb", compresslevel=9, mtime=0) as g:
+        g.write(raw)
+    chain = ["decode csv", "encode normalize", "encode diff", "encode seg", "encode bac adaptive"]
+    names = ["float32", "normalize", "diff", "seg", "dega_adaptive"]
+    meta = {"input_sha256": sha(raw), "input_bytes": len(raw), "stages": {}}
+    for i, name in enumerate(names):
+        data, wrote = dccli(REF_INPUT, chain[: i + 1])
+        meta["stages"][name] = {
+            "chain": " # ".join(chain[: i + 1]), "file_bytes": len(data), "wrote_bytes": wrote[0], "wrote_bits": wrote[1],
+            "sha256": sha(data), "head": data[:8].hex(), "tail": data[-8:].hex(),
+        }
+        if name == "dega_adaptive":
+            with open(os.path.join(HERE, "dega_adaptive.bin"), "wb") as f:
+                f.write(data)
+    data, wrote = dccli(REF_INPUT, chain[:4] + ["encode bac"])
+    meta["stages"]["dega_nonadaptive"] = {"chain": " # ".join(chain[:4] + ["encode bac"]), "file_bytes": len(data),
+                                          "wrote_bytes": wrote[0], "wrote_bits": wrote[1], "sha256": sha(data),
+                                          "head": data[:8].hex(), "tail": data[-8:].hex()}
+    # the full round trip of `make test`
+    full = chain + ["decode bac adaptive", "decode seg", "decode diff", "decode normalize", "encode csv"]
+    data, _ = dccli(REF_INPUT, full)
+    meta["roundtrip_identical"] = (data == raw)
+    with open(os.path.join(HERE, "testfile.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("testfile:", {k: v["sha256"][:12] for k, v in meta["stages"].items()}, "roundtrip", meta["roundtrip_identical"])
+
+
+def kats():
+    cases = {
+        "empty": [], "zero": [0], "zeros96": [0] * 96, "max": [2147483647], "max_zero": [2147483647, 0],
+        "sign_change": [5, -3, 7], "one": [1], "ramp": list(range(0, 64)), "neg_first": [-1],
+        "big_swing": [0, 2147483647, 0, 2147483647], "alternating": [1000, 1001] * 40,
+    }
+    res = {}
+    for name, x in cases.items():
+        for ad in (1, 0):
+            ret, b, n, _ = orc.ref_encode_i32(np.array(x, dtype=np.int32), ad)
+            res["%s/%s" % (name, "adaptive" if ad else "static")] = {"x": x, "adaptive": ad, "ret": int(ret), "hex": b.hex(), "nbits": int(n)}
+    # the empty stream through `encode diff` alone, written to a FILE, is one 0x00 byte (flush quirk, Appendix A.0)
+    with tempfile.NamedTemporaryFile() as tf:
+        data, wrote = dccli(tf.name, ["encode diff"])
+    res["empty_diff_file"] = {"file_hex": data.hex(), "wrote": list(wrote)}
+    with open(os.path.join(HERE, "kats.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print("kats:", len(res))
+
+
+def channels():
+    rng = np.random.default_rng(20241004)
+    sets = {}
+
+    def walk(T, Cn, S, base_lo=10000, base_hi=60000):
+        x = np.zeros((T, Cn), dtype=np.int64)
+        if T:
+            x[0] = rng.integers(base_lo, base_hi, Cn)
+            steps = rng.integers(-S, S + 1, (T, Cn))
+            for t in range(1, T):
+                x[t] = np.clip(x[t - 1] + steps[t], 0, 2**31 - 1)
+        return x.astype(np.int32)
+
+    sets["walk50"] = walk(700, 24, 50)                       # 1-s granularity style (cfg2 shape, shortened)
+    sets["walk300_T96"] = walk(96, 80, 300)                  # 15-min granularity style (cfg3 shape)
+    sets["ragged_small"] = walk(5, 7, 3, 0, 4)               # tiny values: exercises the MPS/LPS swap path
+    wild = rng.integers(0, 2**31, (200, 16)).astype(np.int64)
+    wild[::7] = 0
+    wild[3::11] = 2**31 - 1
+    sets["wild"] = wild.astype(np.int32)                     # full-range jumps: 63-bit codewords, long pending runs
+    bad = walk(50, 8, 50)
+    bad[10, 2] = -5                                          # negative sample -> ERROR_INVALID_VALUE from diff
+    bad[0, 5] = -1
+    sets["with_errors"] = bad
+    sets["zeros"] = np.zeros((300, 4), dtype=np.int32)
+    sets["const"] = np.full((300, 4), 123456, dtype=np.int32)
+    # long channel crossing many model halvings (first at 16 380 coded bits, then every ~8 190)
+    sets["long"] = walk(6000, 3, 50)
+    out = {}
+    for name, x in sets.items():
+        T, Cn = x.shape
+        for ad in (1, 0):
+            streams, bits, errs = [], [], []
+            for c in range(Cn):
+                ret, b, n, _ = orc.ref_encode_i32(np.ascontiguousarray(x[:, c]), ad)
+                streams.append(b)
+                bits.append(n)
+                errs.append(ret)
+                if ret == 0:
+                    rd, y, _ = orc.ref_decode_i32(b, n, T, ad)
+                    assert rd == 0 and (y == x[:, c]).all()
+            cap = max(1, max(len(s) for s in streams))
+            arr = np.zeros((Cn, cap), dtype=np.uint8)
+            for c, s in enumerate(streams):
+                arr[c, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+            tag = "%s.%s" % (name, "ad" if ad else "st")
+            out[tag + ".stream"] = arr
+            out[tag + ".bits"] = np.array(bits, dtype=np.uint64)
+            out[tag + ".err"] = np.array(errs, dtype=np.int32)
+        out[name + ".x"] = x
+    np.savez_compressed(os.path.join(HERE, "channels.npz"), **out)
+    print("channels:", {k: v.shape for k, v in sets.items()})
+
+
+def floats():
+    rng = np.random.default_rng(7)
+    v = np.concatenate([
+        np.array([0.0, -0.0, 0.004, 0.005, 0.0050001, -0.005, 0.015, 0.025, 1.005, 2.675, 301.87, 327.67, 0.12,
+                  -1.0, -0.994, -0.995, -0.996, 1e-30, -1e-30, 21474836.0, 21474836.47, -21474836.48, 1e6 + 0.01,
+                  8388607.5, 8388608.0, 16777216.0, 123456.789], dtype=np.float32),
+        rng.uniform(0, 400, 2000).astype(np.float32).round(2),
+        rng.uniform(-5e4, 5e4, 500).astype(np.float32),
+    ]).astype(np.float32)
+    out = {"v": v}
+    for factor in (100.0, 1.0, 1000.0, 0.5):
+        vf = v[np.abs(v.astype(np.float64) * factor) < 2.0e9]  # in-range subset for this factor
+        out["v_%g" % factor] = vf
+        ret, b, n, _ = orc.ref_run_chain(vf.tobytes(), vf.size * 32, ["encode normalize normalization_factor=%r" % factor])
+        assert ret == 0, (factor, ret)
+        ints = np.frombuffer(b, dtype=">i4").astype(np.int32)
+        out["norm_%g" % factor] = ints
+        ret, b2, n2, _ = orc.ref_run_chain(b, n, ["decode normalize normalization_factor=%r" % factor])
+        assert ret == 0
+        out["denorm_%g" % factor] = np.frombuffer(b2, dtype=np.float32).copy()
+    # out-of-range values make the reference fail with ERROR_INVALID_VALUE (normalize.c:21-22); 2^31 exactly passes
+    edge = np.array([21474836.48 * 1.0001, -21474836.48 * 1.001, 3e9, -3e9], dtype=np.float32)
+    rets = []
+    for e in edge:
+        ret, _, _, _ = orc.ref_run_chain(np.array([e], dtype=np.float32).tobytes(), 32, ["encode normalize"])
+        rets.append(ret)
+    out["edge_v"] = edge
+    out["edge_ret"] = np.array(rets, dtype=np.int64)
+    ret, b, n, _ = orc.ref_run_chain(np.array([21474836.48], dtype=np.float32).tobytes(), 32, ["encode normalize"])
+    out["two31_ret"] = np.array([ret], dtype=np.int64)
+    out["two31_hex"] = np.frombuffer(b, dtype=np.uint8).copy()
+    np.savez_compressed(os.path.join(HERE, "floats.npz"), **out)
+    print("floats:", v.size, "edge rets", rets, "2^31:", ret, b.hex())
+
+
+if __name__ == "__main__":
+    assert orc.have_ref() and os.path.exists(orc.REF_CLI), "build oracle/_ref first: make -C oracle"
+    testfile()
+    kats()
+    channels()
+    floats()
