@@ -1,0 +1,273 @@
+"""data-compressor_amd -- MI355X-native DEGA encode/decode (normalize -> diff -> seg -> bac adaptive) of
+CenterForSecureEnergyInformatics/data-compressor, behind a C ABI.
+
+This Python module is only the thin ctypes binding of `libdega_hip.so` (include/dega_hip.h) that tests/ and bench.py use
+to drive the library with torch-owned device memory and streams.  The product is the shared library (HIP kernels in
+csrc/) and the C host layer in host/ (plugin table mirror of DCLib/inc/enc_dec.h, DCCLI-style driver).
+
+There is NO CPU fallback: if the library is missing, or no GPU is visible, calls raise / return the reference's
+ERROR_LIBRARY_INIT (-10).
+
+The directory name contains a hyphen, so import it with
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("data_compressor_amd", "<repo>/data-compressor_amd/__init__.py")
+or simply `from __graft_entry__ import load_package; dca = load_package()`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdega_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "dega_hip.h")
+
+OK = 0
+ERROR_INVALID_VALUE = -1
+ERROR_INVALID_FORMAT = -3
+ERROR_MEMORY = -6
+ERROR_LIBRARY_INIT = -10
+ERROR_LIBRARY_CALL = -11
+
+_P = C.c_void_p
+_Z = C.c_size_t
+
+_SIGNATURES = {
+    "dega_hip_device_count": (C.c_int, []),
+    "dega_hip_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "dega_hip_destroy": (None, [_P]),
+    "dega_hip_last_error": (C.c_char_p, [_P]),
+    "dega_hip_version": (C.c_char_p, []),
+    "dega_hip_worst_case_bytes": (_Z, [_Z]),
+    "dega_hip_encode_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
+    "dega_hip_decode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
+    "dega_hip_normalize_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, _P, _P, _P]),
+    "dega_hip_denormalize_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, _P, _P]),
+    "dega_hip_compact_offsets_dev": (C.c_int, [_P, _P, _Z, _P, _P]),
+    "dega_hip_compact_gather_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _P]),
+    "dega_hip_synth_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "dega_hip_encode_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P]),
+    "dega_hip_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P]),
+    "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
+    "dega_hip_decode_f32_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P]),
+    "dega_hip_profile": (C.c_int, [_P, C.c_int]),
+    "dega_hip_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_int]),
+}
+
+_lib = None
+
+
+class DegaError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with code %d" % (what, code))
+        self.code = code
+
+
+def library():
+    """Load libdega_hip.so (once).  torch is imported first when available so that both share one HIP runtime."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DegaError(ERROR_LIBRARY_INIT, "loading %s (not built: run __graft_entry__.build())" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (loads torch's libamdhip64 first; same SONAME, one runtime per process)
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def worst_case_bytes(T):
+    return library().dega_hip_worst_case_bytes(T)
+
+
+class Context:
+    """One device context (dega_hip_ctx).  Methods take torch CUDA tensors and enqueue on torch's current stream."""
+
+    def __init__(self, device=0):
+        self._h = _P()
+        self.device = device
+        ret = library().dega_hip_create(device, C.byref(self._h))
+        if ret != OK:
+            self._h = None
+            raise DegaError(ret, "dega_hip_create(device=%d)" % device)
+
+    def close(self):
+        if self._h:
+            library().dega_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return library().dega_hip_last_error(self._h).decode()
+
+    def _check(self, ret, what):
+        if ret != OK:
+            raise DegaError(ret, "%s [%s]" % (what, self.last_error()))
+
+    @staticmethod
+    def _stream():
+        import torch
+        return _P(torch.cuda.current_stream().cuda_stream)
+
+    # ---- device-resident API (torch tensors) ---------------------------------------------------------------------
+    def encode(self, x_tc, adaptive=1, cap=None, out=None, bits=None, err=None):
+        """x_tc: int32 CUDA tensor [T, ld>=C].  Returns (out uint8 [C, cap], bits int64 [C] (bit lengths), err int32 [C])."""
+        import torch
+        T, ld = x_tc.shape
+        Cn = ld
+        assert x_tc.dtype == torch.int32 and x_tc.is_cuda and x_tc.is_contiguous()
+        if cap is None:
+            cap = worst_case_bytes(T)
+        if out is None:
+            out = torch.zeros((Cn, cap), dtype=torch.uint8, device=x_tc.device)
+        if bits is None:
+            bits = torch.zeros(Cn, dtype=torch.int64, device=x_tc.device)
+        if err is None:
+            err = torch.zeros(Cn, dtype=torch.int32, device=x_tc.device)
+        ret = library().dega_hip_encode_dev(self._h, x_tc.data_ptr(), Cn, T, ld, int(adaptive), 32, out.data_ptr(), cap,
+                                            bits.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_encode_dev")
+        return out, bits, err
+
+    def decode(self, streams, bits, T, adaptive=1, x_tc=None, err=None):
+        import torch
+        Cn, cap = streams.shape
+        assert streams.dtype == torch.uint8 and streams.is_cuda and streams.is_contiguous() and bits.dtype == torch.int64
+        if x_tc is None:
+            x_tc = torch.zeros((T, Cn), dtype=torch.int32, device=streams.device)
+        if err is None:
+            err = torch.zeros(Cn, dtype=torch.int32, device=streams.device)
+        ret = library().dega_hip_decode_dev(self._h, streams.data_ptr(), cap, bits.data_ptr(), Cn, T, x_tc.shape[1], int(adaptive), 32,
+                                            x_tc.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_decode_dev")
+        return x_tc, err
+
+    def normalize(self, v_tc, factor=100.0):
+        import torch
+        T, Cn = v_tc.shape
+        assert v_tc.dtype == torch.float32 and v_tc.is_cuda and v_tc.is_contiguous()
+        x = torch.empty((T, Cn), dtype=torch.int32, device=v_tc.device)
+        err = torch.zeros(Cn, dtype=torch.int32, device=v_tc.device)
+        ret = library().dega_hip_normalize_dev(self._h, v_tc.data_ptr(), Cn, T, Cn, float(factor), 32, x.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_normalize_dev")
+        return x, err
+
+    def denormalize(self, x_tc, factor=100.0):
+        import torch
+        T, Cn = x_tc.shape
+        v = torch.empty((T, Cn), dtype=torch.float32, device=x_tc.device)
+        ret = library().dega_hip_denormalize_dev(self._h, x_tc.data_ptr(), Cn, T, Cn, float(factor), 32, v.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_denormalize_dev")
+        return v
+
+    def synth(self, C_, T, seed=1234, c0=0, S=50, device=None, out=None):
+        import torch
+        if out is None:
+            out = torch.empty((T, C_), dtype=torch.int32, device=device or ("cuda:%d" % self.device))
+        ret = library().dega_hip_synth_dev(self._h, out.data_ptr(), C_, T, out.shape[1], seed, c0, S, self._stream())
+        self._check(ret, "dega_hip_synth_dev")
+        return out
+
+    def compact(self, streams, bits):
+        """[C][cap] slabs -> (packed uint8 [total], offsets int64 [C+1])."""
+        import torch
+        Cn, cap = streams.shape
+        offsets = torch.zeros(Cn + 1, dtype=torch.int64, device=streams.device)
+        self._check(library().dega_hip_compact_offsets_dev(self._h, bits.data_ptr(), Cn, offsets.data_ptr(), self._stream()), "compact_offsets")
+        total = int(offsets[-1].item())
+        packed = torch.empty(max(total, 1), dtype=torch.uint8, device=streams.device)
+        self._check(library().dega_hip_compact_gather_dev(self._h, streams.data_ptr(), cap, offsets.data_ptr(), Cn, packed.data_ptr(), self._stream()), "compact_gather")
+        return packed[:total], offsets
+
+    def profile(self, enable=True):
+        library().dega_hip_profile(self._h, 1 if enable else 0)
+
+    def profile_read(self, which=0, reset=True):
+        avg = C.c_double(0.0)
+        n = library().dega_hip_profile_read(self._h, which, C.byref(avg), 1 if reset else 0)
+        return n, avg.value
+
+    # ---- host-pointer API (numpy) ---------------------------------------------------------------------------------
+    def encode_host(self, x_tc, adaptive=1, cap=None):
+        import numpy as np
+        x_tc = np.ascontiguousarray(x_tc, dtype=np.int32)
+        T, Cn = x_tc.shape
+        if cap is None:
+            cap = worst_case_bytes(T)
+        out = np.zeros((Cn, cap), dtype=np.uint8)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_encode_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), 32, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_encode_host")
+        return out, bits, err
+
+    def decode_host(self, streams, bits, T, adaptive=1):
+        import numpy as np
+        streams = np.ascontiguousarray(streams, dtype=np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn, cap = streams.shape
+        x = np.zeros((T, Cn), dtype=np.int32)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_decode_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, int(adaptive), 32, x.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_decode_host")
+        return x, err
+
+    def encode_f32_host(self, v_tc, factor=100.0, adaptive=1, cap=None):
+        import numpy as np
+        v_tc = np.ascontiguousarray(v_tc, dtype=np.float32)
+        T, Cn = v_tc.shape
+        if cap is None:
+            cap = worst_case_bytes(T)
+        out = np.zeros((Cn, cap), dtype=np.uint8)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_encode_f32_host(self._h, v_tc.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), 32, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_encode_f32_host")
+        return out, bits, err
+
+    def decode_f32_host(self, streams, bits, T, factor=100.0, adaptive=1):
+        import numpy as np
+        streams = np.ascontiguousarray(streams, dtype=np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn, cap = streams.shape
+        v = np.zeros((T, Cn), dtype=np.float32)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_decode_f32_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), 32, v.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_decode_f32_host")
+        return v, err
+
+
+def synth_reference(C_, T, seed=1234, c0=0, S=50):
+    """numpy restatement of dega_synth_kernel (csrc/dega_kernels.hpp) -- the workload definition of SURVEY.md 8d."""
+    import numpy as np
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    x = np.zeros((T, C_), dtype=np.int32)
+    for c in range(C_):
+        key = mix((seed ^ (((c0 + c) * 0xD1342543DE82EF95) & M)) & M)
+        v = 10000 + mix(key) % 50000
+        for t in range(T):
+            if t > 0:
+                v += mix((key + t) & M) % (2 * S + 1) - S
+                v = min(max(v, 0), 2**31 - 1)
+            x[t, c] = v
+    return x

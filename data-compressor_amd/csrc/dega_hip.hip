@@ -1,0 +1,498 @@
+// dega_hip.hip -- host side of libdega_hip.so: the C ABI declared in include/dega_hip.h.
+//
+// Owns one context per device (division table in HBM, scratch buffers for the host-pointer entry points, optional
+// hipEvent timing of the hot kernels) and launches the kernels of dega_kernels.hpp.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC dega_hip.hip -o libdega_hip.so      (see csrc/Makefile)
+#include <hip/hip_runtime.h>
+
+#include "../../include/dega_hip.h"
+#include "dega_kernels.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+using namespace dg;
+
+struct dega_hip_ctx
+{
+  int device;
+  DivEntry *div_table; // device
+  char last_error[256];
+  bool profile;
+  std::vector<hipEvent_t> ev[2]; // start/stop pairs per kernel kind (0 encode, 1 decode)
+  std::vector<hipEvent_t> ev_pool;
+};
+
+static int fail(dega_hip_ctx *ctx, int code, const char *what, hipError_t e)
+{
+  if (ctx != nullptr)
+    snprintf(ctx->last_error, sizeof(ctx->last_error), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
+  return code;
+}
+
+#define HIP_TRY(ctx, expr, code)                      \
+  do                                                  \
+  {                                                   \
+    const hipError_t e_ = (expr);                     \
+    if (e_ != hipSuccess)                             \
+      return fail((ctx), (code), #expr, e_);          \
+  } while (0)
+
+static void build_div_table(std::vector<DivEntry> &tab)
+{
+  tab.assign(DIV_TABLE_SIZE, DivEntry{0u, 0u});
+  for (uint32_t t = 3; t < DIV_TABLE_SIZE; t++)
+  {
+    uint32_t L = 0;
+    while ((1u << L) < t)
+      L++;
+    const unsigned __int128 num = (unsigned __int128)1 << (30 + L);
+    tab[t].magic = (uint32_t)((num + t - 1) / t);
+    tab[t].shift = L - 2;
+  }
+}
+
+extern "C" int dega_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+extern "C" const char *dega_hip_version(void)
+{
+  return "dega-hip 0.1 (gfx950)";
+}
+
+extern "C" size_t dega_hip_worst_case_bytes(size_t T)
+{
+  // seg: <= 65 bits per sample (seg.c:18-19).  bac: a coded bit costs at most log2(cum[0]/freq) <= 14 bits in the worst
+  // model state, but over a whole stream the adaptive coder stays within a few percent of 1 bit/bit plus the counts'
+  // learning cost; the static coder (frequencies 1:1:1) costs log2(3) bits per bit.  2 output bits per seg bit covers both.
+  const size_t bits = T * 65 * 2 + 64;
+  return ((bits + 7) / 8 + 16 + 3) & ~(size_t)3;
+}
+
+extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
+{
+  if (out == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return DEGA_ERROR_LIBRARY_INIT; // no CPU fallback: fail loudly
+  dega_hip_ctx *ctx = new dega_hip_ctx();
+  ctx->device = device;
+  ctx->div_table = nullptr;
+  ctx->last_error[0] = '\0';
+  ctx->profile = false;
+  if (hipSetDevice(device) != hipSuccess)
+  {
+    delete ctx;
+    return DEGA_ERROR_LIBRARY_INIT;
+  }
+  std::vector<DivEntry> tab;
+  build_div_table(tab);
+  if (hipMalloc((void **)&ctx->div_table, tab.size() * sizeof(DivEntry)) != hipSuccess)
+  {
+    delete ctx;
+    return DEGA_ERROR_MEMORY;
+  }
+  if (hipMemcpy(ctx->div_table, tab.data(), tab.size() * sizeof(DivEntry), hipMemcpyHostToDevice) != hipSuccess)
+  {
+    hipFree(ctx->div_table);
+    delete ctx;
+    return DEGA_ERROR_LIBRARY_INIT;
+  }
+  *out = ctx;
+  return DEGA_OK;
+}
+
+extern "C" void dega_hip_destroy(dega_hip_ctx *ctx)
+{
+  if (ctx == nullptr)
+    return;
+  hipSetDevice(ctx->device);
+  for (int k = 0; k < 2; k++)
+    for (hipEvent_t e : ctx->ev[k])
+      hipEventDestroy(e);
+  hipFree(ctx->div_table);
+  delete ctx;
+}
+
+extern "C" const char *dega_hip_last_error(const dega_hip_ctx *ctx)
+{
+  return ctx == nullptr ? "no context" : ctx->last_error;
+}
+
+extern "C" int dega_hip_profile(dega_hip_ctx *ctx, int enable)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  ctx->profile = enable != 0;
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_ms, int reset)
+{
+  if (ctx == nullptr || which < 0 || which > 1 || avg_ms == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  std::vector<hipEvent_t> &v = ctx->ev[which];
+  double sum = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < v.size(); i += 2)
+  {
+    float ms = 0.f;
+    if (hipEventSynchronize(v[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess)
+    {
+      sum += ms;
+      n++;
+    }
+  }
+  *avg_ms = n ? sum / n : 0.0;
+  if (reset)
+  {
+    for (hipEvent_t e : v)
+      hipEventDestroy(e);
+    v.clear();
+  }
+  return n;
+}
+
+// RAII-free helper: brackets a launch with events on the launch's own stream when profiling is on
+struct LaunchTimer
+{
+  dega_hip_ctx *ctx;
+  int which;
+  hipStream_t s;
+  LaunchTimer(dega_hip_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st)
+  {
+    if (ctx->profile)
+    {
+      hipEvent_t e;
+      if (hipEventCreate(&e) == hipSuccess)
+      {
+        hipEventRecord(e, s);
+        ctx->ev[which].push_back(e);
+      }
+    }
+  }
+  ~LaunchTimer()
+  {
+    if (ctx->profile && (ctx->ev[which].size() & 1u))
+    {
+      hipEvent_t e;
+      if (hipEventCreate(&e) == hipSuccess)
+      {
+        hipEventRecord(e, s);
+        ctx->ev[which].push_back(e);
+      }
+      else
+      {
+        hipEventDestroy(ctx->ev[which].back());
+        ctx->ev[which].pop_back();
+      }
+    }
+  }
+};
+
+static int check_shape(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t cap, int valuesize)
+{
+  (void)T;
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (valuesize != 32)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "valuesize must be 32 for the [T][C] int32 layout", hipSuccess);
+  if (ld < C)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "ld < C", hipSuccess);
+  if (cap % 4 != 0 || cap / 4 > 0xFFFFFFFFull)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "cap must be a multiple of 4 (and < 16 GiB)", hipSuccess);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                   uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  EncodeArgs a;
+  a.x = x_tc;
+  a.C = C;
+  a.T = T;
+  a.ld = ld;
+  a.out = out;
+  a.cap = cap;
+  a.out_bits = out_bits;
+  a.err = err;
+  a.div_table = ctx->div_table;
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 0, s);
+    if (adaptive)
+      hipLaunchKernelGGL(dega_encode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
+    else
+      hipLaunchKernelGGL(dega_encode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                   int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
+{
+  (void)in; (void)in_bits; (void)adaptive; (void)x_tc; (void)err; (void)stream;
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  return fail(ctx, DEGA_ERROR_LIBRARY_CALL, "decode kernel not built yet", hipSuccess);
+}
+
+static dim3 rowsplit_grid(size_t C, size_t T)
+{
+  // enough blocks to fill the chip: columns x row-chunks
+  const unsigned gx = (unsigned)((C + BLOCK - 1) / BLOCK);
+  unsigned gy = 1;
+  while ((size_t)gx * gy < 2048 && gy < 1024 && (size_t)gy * 64 < T)
+    gy *= 2;
+  return dim3(gx, gy);
+}
+
+extern "C" int dega_hip_normalize_dev(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int valuesize,
+                                      int32_t *x_tc, int32_t *err, void *stream)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, 0, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipMemsetAsync(err, 0, C * sizeof(int32_t), s), DEGA_ERROR_LIBRARY_CALL);
+  if (T == 0)
+    return DEGA_OK;
+  NormalizeArgs a{v_tc, x_tc, C, T, ld, factor, err};
+  hipLaunchKernelGGL(dega_normalize_kernel, rowsplit_grid(C, T), dim3(BLOCK), 0, s, a);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_denormalize_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, float factor, int valuesize,
+                                        float *v_tc, void *stream)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, 0, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0 || T == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DenormalizeArgs a{x_tc, v_tc, C, T, ld, factor};
+  hipLaunchKernelGGL(dega_denormalize_kernel, rowsplit_grid(C, T), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+// exclusive prefix sum of ceil(bits/8) over channels: one block, chunked (C is at most a few million; not a hot path)
+__global__ void __launch_bounds__(1024) dega_offsets_kernel(const uint64_t *bits, size_t C, uint64_t *offsets)
+{
+  __shared__ uint64_t part[1024];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < C; base += 1024)
+  {
+    const size_t i = base + threadIdx.x;
+    const uint64_t v = i < C ? (bits[i] + 7) / 8 : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1)
+    {
+      const uint64_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < C)
+      offsets[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    offsets[C] = carry;
+}
+
+extern "C" int dega_hip_compact_offsets_dev(dega_hip_ctx *ctx, const uint64_t *bits, size_t C, uint64_t *offsets, void *stream)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bits, C, offsets);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_compact_gather_dev(dega_hip_ctx *ctx, const uint8_t *slabs, size_t cap, const uint64_t *offsets, size_t C,
+                                           uint8_t *packed, void *stream)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  GatherArgs a{slabs, cap, offsets, C, packed};
+  hipLaunchKernelGGL(dega_gather_kernel, dim3((unsigned)((C + WAVES - 1) / WAVES)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_synth_dev(dega_hip_ctx *ctx, int32_t *x_tc, size_t C, size_t T, size_t ld, uint64_t seed, uint64_t c0, uint32_t S, void *stream)
+{
+  if (ctx == nullptr || ld < C)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0 || T == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  SynthArgs a{x_tc, C, T, ld, seed, c0, S};
+  hipLaunchKernelGGL(dega_synth_kernel, dim3((unsigned)((C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+// ---- host-pointer entry points ---------------------------------------------------------------------------------------
+
+struct DevBuf
+{
+  void *p = nullptr;
+  ~DevBuf()
+  {
+    if (p != nullptr)
+      hipFree(p);
+  }
+  hipError_t alloc(size_t n)
+  {
+    return hipMalloc(&p, n > 0 ? n : 1);
+  }
+};
+
+extern "C" int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                    uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dx, dout, dbits, derr;
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                    int adaptive, int valuesize, int32_t *x_tc, int32_t *err)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dx, din, dbits, derr;
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, T * ld * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
+                                        uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dv, dx, dout, dbits, derr, dnerr;
+  HIP_TRY(ctx, dv.alloc(T * ld * sizeof(float)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dnerr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(dv.p, v_tc, T * ld * sizeof(float), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_normalize_dev(ctx, (const float *)dv.p, C, T, ld, factor, valuesize, (int32_t *)dx.p, (int32_t *)dnerr.p, nullptr)) != DEGA_OK)
+    return ret;
+  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  std::vector<int32_t> nerr(C);
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(nerr.data(), dnerr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  for (size_t c = 0; c < C; c++) // the first failing stage of the chain reports (normalize runs before diff)
+    if (nerr[c] != DEGA_OK)
+      err[c] = nerr[c];
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                        float factor, int adaptive, int valuesize, float *v_tc, int32_t *err)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dv, dx, din, dbits, derr;
+  HIP_TRY(ctx, dv.alloc(T * ld * sizeof(float)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  if ((ret = dega_hip_denormalize_dev(ctx, (const int32_t *)dx.p, C, T, ld, factor, valuesize, (float *)dv.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(v_tc, dv.p, T * ld * sizeof(float), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}

@@ -1,0 +1,113 @@
+/* dega_hip.h -- C ABI of libdega_hip.so: the MI355X (gfx950) implementation of DCLib's DEGA hot path.
+ *
+ * This is the drop-in boundary for the path  normalize -> diff -> seg -> bac [adaptive]  (and its inverse) of
+ * CenterForSecureEnergyInformatics/data-compressor.  Plain C: pointers, sizes and integer codes only; no torch types.
+ * Paths below are relative to the reference's DataCompressor/ directory.
+ *
+ * What each entry point replaces in the reference:
+ *   dega_hip_encode_*   the stage functions  EncodeDifferential (DCLib/src/diff.c:9-23)  ->  EncodeSEG (DCLib/src/seg.c:31-43)
+ *                       ->  EncodeBAC (DCLib/src/bac.c:147-166)  run back to back by DCCLI's stage loop
+ *                       (DCCLI/src/cli.c:430-466) -- one call codes C independent channels instead of one.
+ *   dega_hip_decode_*   DecodeBAC (bac.c:244-263) -> DecodeSEG (seg.c:82-94) -> DecodeDifferential (diff.c:25-37).
+ *   dega_hip_normalize_* / dega_hip_denormalize_*   Normalize / Denormalize (DCLib/src/normalize.c:9-27, :29-41).
+ *   the bit format       DCIOLib/src/bit_file_buffer.c:220-248, 297-308 (MSB-first bits, big-endian values).
+ * The reference-side binding (a row in encoders_decoders[], DCLib/src/enc_dec.c:51-60, whose enc_dec_function_t
+ * (DCLib/inc/enc_dec.h:11) pulls the stream out of in_bit_buf, calls these, and pushes the result into out_bit_buf)
+ * is shown in INTEGRATION.md and implemented in data-compressor_amd/host/.
+ *
+ * Per channel the produced bytes and the exact bit length equal what the reference's chain
+ *     encode diff # encode seg # encode bac [adaptive]        (valuesize 32)
+ * produces for that channel alone; errors are per channel and use the reference's codes (common/inc/err_codes.h:8-32).
+ *
+ * Layouts
+ *   samples  x_tc : int32 [T][ld]   time-major, channel c in column c (ld >= C elements per row; lanes = channels read
+ *                                   consecutive int32 -> coalesced 256-byte rows per wavefront)
+ *   streams  out  : uint8 [C][cap]  channel c's stream starts at out + c*cap; cap is a multiple of 4
+ *            bits : uint64 [C]      exact stream length in bits (the last byte is zero padded)
+ *            err  : int32 [C]       DEGA_OK or a negative reference error code for that channel
+ * "dev" entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t passed as void*, NULL = default
+ * stream) without synchronising.  "host" entry points take host pointers and are synchronous.
+ * There is no CPU fallback: without a usable GPU every call fails with DEGA_ERROR_LIBRARY_INIT.
+ */
+#ifndef DEGA_HIP_H
+#define DEGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same values as the reference's common/inc/err_codes.h:8-32 */
+#define DEGA_OK 0
+#define DEGA_ERROR_INVALID_VALUE (-1)   /* diff/normalize range violation (diff.c:17-18, normalize.c:21-22), bad argument */
+#define DEGA_ERROR_INVALID_FORMAT (-3)  /* undecodable stream (seg.c:55-56, bac.c:171-186) */
+#define DEGA_ERROR_MEMORY (-6)          /* out of device memory, or a channel's stream does not fit its `cap` bytes */
+#define DEGA_ERROR_LIBRARY_INIT (-10)   /* no GPU / HIP runtime failure at init */
+#define DEGA_ERROR_LIBRARY_CALL (-11)   /* HIP failure during a call */
+
+typedef struct dega_hip_ctx dega_hip_ctx; /* one context = one device; not thread safe (like the reference's codecs) */
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------- */
+int dega_hip_device_count(void);                            /* number of visible GPUs, 0 if none / no runtime */
+int dega_hip_create(int device, dega_hip_ctx **ctx);        /* DEGA_OK or DEGA_ERROR_LIBRARY_INIT / _MEMORY */
+void dega_hip_destroy(dega_hip_ctx *ctx);
+const char *dega_hip_last_error(const dega_hip_ctx *ctx);   /* text of the last failure on this context ("" if none) */
+const char *dega_hip_version(void);
+
+/* Bytes per channel that always suffice for T samples (seg worst case 65 bits/sample, bac expansion, EOF + flush). */
+size_t dega_hip_worst_case_bytes(size_t T);
+
+/* ---- DEGA encode / decode, device pointers ----------------------------------------------------------------------- */
+/* valuesize must be 32 (the only width the [T][C] int32 layout carries); adaptive: 0 = `bac`, 1 = `bac adaptive`. */
+int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                        uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
+/* in_bits[c] is the exact bit length, or 8*bytes when the stream comes from a zero-padded file.  Decodes exactly T
+   samples per channel; a stream holding fewer or more yields DEGA_ERROR_INVALID_FORMAT for that channel. */
+int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                        int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream);
+
+/* ---- float entry / exit (normalize.c), device pointers ----------------------------------------------------------- */
+/* v: float32 [T][ld] -> x: int32 [T][ld]; err[c] = DEGA_ERROR_INVALID_VALUE if any sample of channel c fails the range check. */
+int dega_hip_normalize_dev(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int valuesize,
+                           int32_t *x_tc, int32_t *err, void *stream);
+int dega_hip_denormalize_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, float factor, int valuesize,
+                             float *v_tc, void *stream);
+
+/* ---- stream compaction: [C][cap] slabs -> one contiguous buffer --------------------------------------------------- */
+/* offsets[c] (uint64 [C+1], device) = byte offset of channel c in `packed`; a channel occupies ceil(bits/8) bytes.
+   Two steps so that the caller can size `packed`: _offsets fills offsets (exclusive prefix sum, offsets[C] = total),
+   _gather copies. */
+int dega_hip_compact_offsets_dev(dega_hip_ctx *ctx, const uint64_t *bits, size_t C, uint64_t *offsets, void *stream);
+int dega_hip_compact_gather_dev(dega_hip_ctx *ctx, const uint8_t *slabs, size_t cap, const uint64_t *offsets, size_t C,
+                                uint8_t *packed, void *stream);
+
+/* ---- synthetic load profiles: deterministic integer random walk, generated on the device ------------ */
+/* x[c][0] = 10000 + h(c) mod 50000;  x[c][t] = clamp(x[c][t-1] + (h(c,t) mod (2S+1)) - S, 0, 2^31-1);  channel ids start at
+   c0 (so that rank r of a multi-GPU job generates its own channel range). */
+int dega_hip_synth_dev(dega_hip_ctx *ctx, int32_t *x_tc, size_t C, size_t T, size_t ld, uint64_t seed, uint64_t c0, uint32_t S, void *stream);
+
+/* ---- host-pointer convenience (H2D, kernels, D2H; synchronous) ---------------------------------------------------- */
+int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                         uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
+int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                         int adaptive, int valuesize, int32_t *x_tc, int32_t *err);
+/* float32 channels in, DEGA streams out: normalize + encode fused on the device (and the inverse). */
+int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
+                             uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
+int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                             float factor, int adaptive, int valuesize, float *v_tc, int32_t *err);
+
+/* ---- measurement hook ---------------------------------------------------------------------------------------------- */
+/* Average duration in milliseconds of the encode (which=0) / decode (which=1) kernel launches enqueued since the last
+   reset, measured with hipEvents on the stream each launch used (enabled with dega_hip_profile(ctx, 1)); returns the
+   number of launches measured.  Used by bench.py for the roofline figure. */
+int dega_hip_profile(dega_hip_ctx *ctx, int enable);
+int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

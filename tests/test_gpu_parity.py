@@ -1,0 +1,176 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (libdega_hip.so), against
+  * the golden vectors generated from the compiled reference (tests/golden/), and
+  * the oracle (oracle/liboracle.so) on the same seeded inputs.
+Bit-exact: stream bytes, exact bit lengths and per-channel error codes."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dca():
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(dca):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
+    c = dca.Context(0)
+    yield c
+    c.close()
+
+
+def assert_streams_equal(out, bits, err, want_out, want_bits, want_err, tag=""):
+    assert (err == want_err).all(), (tag, err[:8], want_err[:8])
+    ok = want_err == 0
+    assert (bits[ok] == want_bits[ok]).all(), tag
+    for c in np.nonzero(ok)[0]:
+        nb = (int(want_bits[c]) + 7) // 8
+        assert out[c, :nb].tobytes() == want_out[c, :nb].tobytes(), (tag, int(c))
+
+
+def test_golden_channel_batches(ctx):
+    z = np.load(os.path.join(GOLDEN, "channels.npz"))
+    names = sorted(k[:-2] for k in z.files if k.endswith(".x"))
+    for name in names:
+        x = z[name + ".x"]
+        for ad, tag in ((1, "ad"), (0, "st")):
+            out, bits, err = ctx.encode_host(x, adaptive=ad)
+            assert_streams_equal(out, bits, err, z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)],
+                                 z["%s.%s.err" % (name, tag)], (name, tag))
+
+
+def test_kats(ctx):
+    with open(os.path.join(GOLDEN, "kats.json")) as f:
+        kats = json.load(f)
+    for name, k in kats.items():
+        if "x" not in k:
+            continue
+        x = np.array(k["x"], dtype=np.int32).reshape(-1, 1)
+        out, bits, err = ctx.encode_host(x, adaptive=k["adaptive"], cap=64 + 4 * ((x.size * 20 + 3) // 4))
+        assert int(err[0]) == k["ret"], name
+        if k["ret"] == 0:
+            assert int(bits[0]) == k["nbits"], name
+            assert out[0, : (k["nbits"] + 7) // 8].tobytes().hex() == k["hex"], name
+
+
+def test_reference_test_file(ctx):
+    """The reference's own test file through normalize + DEGA on the GPU equals the canonical stream of `make test`."""
+    with gzip.open(os.path.join(GOLDEN, "input.txt.gz"), "rb") as f:
+        v = np.array(f.read().split(), dtype=np.float64).astype(np.float32)
+    with open(os.path.join(GOLDEN, "dega_adaptive.bin"), "rb") as f:
+        want = f.read()
+    with open(os.path.join(GOLDEN, "testfile.json")) as f:
+        meta = json.load(f)["stages"]["dega_adaptive"]
+    # 70 copies: more than one wave, a ragged last wave
+    vt = np.repeat(v.reshape(-1, 1), 70, axis=1)
+    out, bits, err = ctx.encode_f32_host(vt, factor=100.0, adaptive=1, cap=4 * ((len(want) + 64) // 4))
+    assert (err == 0).all()
+    assert (bits == meta["wrote_bytes"] * 8 + meta["wrote_bits"]).all()
+    for c in (0, 1, 63, 64, 69):
+        assert out[c, : len(want)].tobytes() == want
+
+
+def test_normalize_kernel_golden(ctx):
+    import torch
+    z = np.load(os.path.join(GOLDEN, "floats.npz"))
+    for factor in (100.0, 1.0, 1000.0, 0.5):
+        v = z["v_%g" % factor]
+        vt = torch.from_numpy(np.stack([v, v[::-1].copy()], axis=1)).cuda()
+        x, err = ctx.normalize(vt, factor)
+        torch.cuda.synchronize()
+        assert (err.cpu().numpy() == 0).all()
+        xn = x.cpu().numpy()
+        assert (xn[:, 0] == z["norm_%g" % factor]).all() and (xn[::-1, 1] == z["norm_%g" % factor]).all(), factor
+        d = ctx.denormalize(x, factor).cpu().numpy()
+        assert d[:, 0].tobytes() == z["denorm_%g" % factor].tobytes(), factor
+    edge = np.concatenate([z["edge_v"], np.array([21474836.48, 1.0], dtype=np.float32)])
+    x, err = ctx.normalize(torch.from_numpy(edge.reshape(1, -1).copy()).cuda(), 100.0)
+    torch.cuda.synchronize()
+    assert err.cpu().numpy().tolist() == [-1, -1, -1, -1, 0, 0]
+    assert x.cpu().numpy()[0, 4] == -2147483648 and x.cpu().numpy()[0, 5] == 100
+
+
+def test_random_batch_vs_oracle(ctx):
+    rng = np.random.default_rng(42)
+    for (T, Cn, S, ld_pad) in ((300, 1000, 50, 0), (96, 3000, 300, 0), (1000, 130, 5000, 7), (17, 64, 2, 0), (1, 257, 1000, 0)):
+        x = np.zeros((T, Cn), dtype=np.int64)
+        x[0] = rng.integers(0, 60000, Cn)
+        steps = rng.integers(-S, S + 1, (T, Cn)) * rng.integers(0, 3, Cn)[None, :]
+        for t in range(1, T):
+            x[t] = np.clip(x[t - 1] + steps[t], 0, 2**31 - 1)
+        x = x.astype(np.int32)
+        for ad in (1, 0):
+            cap = 4 * ((T * 16 + 67) // 4) if S < 1000 else None
+            want = orc.encode_batch_tc(x, ad, cap=cap)
+            if ld_pad:
+                import torch
+                xt = torch.zeros((T, Cn + ld_pad), dtype=torch.int32, device="cuda")
+                xt[:, :Cn] = torch.from_numpy(x).cuda()
+                out, bits, err = ctx.encode(xt, adaptive=ad, cap=want[0].shape[1])
+                torch.cuda.synchronize()
+                got = (out.cpu().numpy()[:Cn], bits.cpu().numpy().astype(np.uint64)[:Cn], err.cpu().numpy()[:Cn])
+            else:
+                got = ctx.encode_host(x, adaptive=ad, cap=want[0].shape[1])
+            assert_streams_equal(*got, *want, tag=(T, Cn, S, ad))
+
+
+def test_slab_too_small_reports_memory_error(ctx):
+    x = np.cumsum(np.random.default_rng(3).integers(-50, 51, (400, 65)), axis=0).astype(np.int32) + 30000
+    out, bits, err = ctx.encode_host(x, adaptive=1, cap=64)
+    assert (err == -6).all()  # ERROR_MEMORY: 400 samples cannot fit 64 bytes
+    out2, bits2, err2 = ctx.encode_host(x, adaptive=1)
+    assert (err2 == 0).all() and (bits2 == bits).all()  # the length is still reported
+    assert (out[:, :60] == out2[:, :60]).all()
+
+
+def test_synth_matches_numpy_definition(ctx, dca):
+    import torch
+    x = ctx.synth(130, 60, seed=1234, c0=5, S=50)
+    torch.cuda.synchronize()
+    assert (x.cpu().numpy() == dca.synth_reference(130, 60, seed=1234, c0=5, S=50)).all()
+    x = ctx.synth(70, 96, seed=99, c0=0, S=300)
+    torch.cuda.synchronize()
+    assert (x.cpu().numpy() == dca.synth_reference(70, 96, seed=99, c0=0, S=300)).all()
+
+
+def test_compaction(ctx):
+    import torch
+    x = ctx.synth(300, 200, seed=7)
+    out, bits, err = ctx.encode(x, adaptive=1)
+    packed, offsets = ctx.compact(out, bits)
+    torch.cuda.synchronize()
+    o, b, p, off = out.cpu().numpy(), bits.cpu().numpy(), packed.cpu().numpy(), offsets.cpu().numpy()
+    nbytes = (b + 7) // 8
+    assert (off[1:] - off[:-1] == nbytes).all() and off[0] == 0
+    for c in (0, 1, 63, 64, 255, 256, 299):
+        assert p[off[c]: off[c + 1]].tobytes() == o[c, : nbytes[c]].tobytes()
+
+
+def test_larger_batch_sampled_against_oracle(ctx):
+    """8192 channels x 3000 samples (crosses the first model halvings): every 97th channel compared with the oracle,
+    all lengths compared with the lengths the oracle gives for those channels, all statuses zero."""
+    import torch
+    Cn, T = 8192, 3000
+    x = ctx.synth(Cn, T, seed=1234, S=50)
+    cap = 4 * ((T * 3 + 67) // 4)
+    out, bits, err = ctx.encode(x, adaptive=1, cap=cap)
+    torch.cuda.synchronize()
+    assert (err.cpu().numpy() == 0).all()
+    sel = np.arange(0, Cn, 97)
+    xs = x[:, torch.from_numpy(sel).cuda()].cpu().numpy()
+    want = orc.encode_batch_tc(xs, 1, cap=cap)
+    got_out = out.cpu().numpy()[sel]
+    got_bits = bits.cpu().numpy().astype(np.uint64)[sel]
+    assert_streams_equal(got_out, got_bits, np.zeros(len(sel), dtype=np.int32), *want, tag="large")

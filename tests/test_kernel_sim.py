@@ -1,0 +1,81 @@
+"""Kernel LOGIC check without a GPU: the real kernel source (data-compressor_amd/csrc/dega_kernels.hpp) compiled by g++
+under the thread-per-lane emulator of tests/sim/ and compared with the golden vectors.  This is a debugging aid for
+the build container (ring indexing, phase control, termination); the parity tests proper are the -m gpu tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIM_DIR = os.path.join(HERE, "sim")
+GOLDEN = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    subprocess.run(["make", "-s", "-C", SIM_DIR], check=True)
+    S = C.CDLL(os.path.join(SIM_DIR, "libdega_sim.so"))
+    S.sim_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    S.sim_synth.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32]
+    S.sim_normalize.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]
+    S.sim_denormalize.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p]
+    return S
+
+
+def sim_encode(S, x, ad, cap=None):
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    T, Cn = x.shape
+    if cap is None:
+        cap = (orc.lib().orc_dega_worst_case_bytes(T) + 3) & ~3
+    out = np.zeros((Cn, cap), dtype=np.uint8)
+    bits = np.zeros(Cn, dtype=np.uint64)
+    err = np.zeros(Cn, dtype=np.int32)
+    S.sim_encode(x.ctypes.data, Cn, T, Cn, ad, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+    return out, bits, err
+
+
+def test_encode_kernel_logic_on_golden_sets(sim):
+    z = np.load(os.path.join(GOLDEN, "channels.npz"))
+    for name in ("walk50", "walk300_T96", "ragged_small", "wild", "with_errors", "zeros"):
+        x = z[name + ".x"]
+        for ad, tag in ((1, "ad"), (0, "st")):
+            out, bits, err = sim_encode(sim, x, ad)
+            gs, gb, ge = z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)], z["%s.%s.err" % (name, tag)]
+            assert (err == ge).all(), name
+            ok = ge == 0
+            assert (bits[ok] == gb[ok]).all(), name
+            for c in np.nonzero(ok)[0]:
+                nb = (int(gb[c]) + 7) // 8
+                assert out[c, :nb].tobytes() == gs[c, :nb].tobytes(), (name, tag, c)
+
+
+def test_encode_kernel_logic_multiwave_vs_oracle(sim):
+    rng = np.random.default_rng(11)
+    T, Cn = 120, 300  # two workgroups, a ragged last wave
+    x = np.cumsum(rng.integers(-80, 81, (T, Cn)) * rng.integers(0, 3, Cn)[None, :], axis=0) + 40000
+    x = x.astype(np.int32)
+    out, bits, err = sim_encode(sim, x, 1)
+    o2, b2, e2 = orc.encode_batch_tc(x, 1, cap=out.shape[1])
+    assert (err == e2).all() and (bits == b2).all() and (out == o2).all()
+
+
+def test_synth_and_normalize_kernels(sim):
+    from __graft_entry__ import load_package
+    dca = load_package()
+    x = np.zeros((40, 70), dtype=np.int32)
+    sim.sim_synth(x.ctypes.data, 70, 40, 70, 1234, 3, 50)
+    assert (x == dca.synth_reference(70, 40, seed=1234, c0=3, S=50)).all()
+    z = np.load(os.path.join(GOLDEN, "floats.npz"))
+    v = z["v_100"]
+    vt = np.ascontiguousarray(np.stack([v, v], axis=1))
+    xi = np.zeros(vt.shape, dtype=np.int32)
+    err = np.zeros(2, dtype=np.int32)
+    sim.sim_normalize(vt.ctypes.data, 2, v.size, 2, 100.0, xi.ctypes.data, err.ctypes.data)
+    assert (err == 0).all() and (xi[:, 0] == z["norm_100"]).all()
+    back = np.zeros(vt.shape, dtype=np.float32)
+    sim.sim_denormalize(xi.ctypes.data, 2, v.size, 2, 100.0, back.ctypes.data)
+    assert back[:, 1].tobytes() == z["denorm_100"].tobytes()
