@@ -102,6 +102,10 @@ def test_normalize_kernel_golden(ctx):
     assert x.cpu().numpy()[0, 4] == -2147483648 and x.cpu().numpy()[0, 5] == 100
 
 
+def ctx_worst(T):
+    return load_package().worst_case_bytes(T)
+
+
 def test_random_batch_vs_oracle(ctx):
     rng = np.random.default_rng(42)
     for (T, Cn, S, ld_pad) in ((300, 1000, 50, 0), (96, 3000, 300, 0), (1000, 130, 5000, 7), (17, 64, 2, 0), (1, 257, 1000, 0)):
@@ -112,7 +116,7 @@ def test_random_batch_vs_oracle(ctx):
             x[t] = np.clip(x[t - 1] + steps[t], 0, 2**31 - 1)
         x = x.astype(np.int32)
         for ad in (1, 0):
-            cap = 4 * ((T * 16 + 67) // 4) if S < 1000 else None
+            cap = 4 * ((T * 16 + 67) // 4) if S < 1000 else ctx_worst(T)
             want = orc.encode_batch_tc(x, ad, cap=cap)
             if ld_pad:
                 import torch

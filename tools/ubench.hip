@@ -26,7 +26,7 @@ constexpr int ITERS = 2000;
     float g = (float)a + 1.0f;                                                                \
     for (int i = 0; i < ITERS; i++)                                                           \
     {                                                                                         \
-      asm volatile(R64(INSTR "\n\t") : "+v"(a), "+v"(b), "+v"(c), "+v"(w), "+v"(z), "+v"(d), "+v"(e), "+v"(f), "+v"(g)::"vcc"); \
+      asm volatile(R64(INSTR "\n\t") : "+v"(a), "+v"(b), "+v"(c), "+v"(w), "+v"(z), "+v"(d), "+v"(e), "+v"(f), "+v"(g)::"vcc", "s4", "s5"); \
     }                                                                                         \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + (uint32_t)w + (uint32_t)z + (uint32_t)d + (uint32_t)g; \
   }
@@ -129,6 +129,7 @@ struct Test { const char *name; kern_t k; int instr_per_rep; };
 
 int main()
 {
+  setvbuf(stdout, NULL, _IONBF, 0);
   uint32_t *out;
   uint64_t *clk;
   CHECK(hipMalloc(&out, 4096 * 256 * 4));
