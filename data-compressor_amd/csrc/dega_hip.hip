@@ -19,7 +19,7 @@ using namespace dg;
 struct dega_hip_ctx
 {
   int device;
-  DivEntry *div_table; // device
+  uint32_t *div_magic; // device, DIV_TABLE_SIZE entries
   char last_error[256];
   bool profile;
   std::vector<hipEvent_t> ev[2]; // start/stop pairs per kernel kind (0 encode, 1 decode)
@@ -41,17 +41,16 @@ static int fail(dega_hip_ctx *ctx, int code, const char *what, hipError_t e)
       return fail((ctx), (code), #expr, e_);          \
   } while (0)
 
-static void build_div_table(std::vector<DivEntry> &tab)
+static void build_div_table(std::vector<uint32_t> &tab)
 {
-  tab.assign(DIV_TABLE_SIZE, DivEntry{0u, 0u});
+  tab.assign(DIV_TABLE_SIZE, 0u);
   for (uint32_t t = 3; t < DIV_TABLE_SIZE; t++)
   {
     uint32_t L = 0;
     while ((1u << L) < t)
       L++;
     const unsigned __int128 num = (unsigned __int128)1 << (30 + L);
-    tab[t].magic = (uint32_t)((num + t - 1) / t);
-    tab[t].shift = L - 2;
+    tab[t] = (uint32_t)((num + t - 1) / t); // ceil(2^(30+L) / t); the shift L - 2 is recomputed from t (div_shift)
   }
 }
 
@@ -87,7 +86,7 @@ extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
     return DEGA_ERROR_LIBRARY_INIT; // no CPU fallback: fail loudly
   dega_hip_ctx *ctx = new dega_hip_ctx();
   ctx->device = device;
-  ctx->div_table = nullptr;
+  ctx->div_magic = nullptr;
   ctx->last_error[0] = '\0';
   ctx->profile = false;
   if (hipSetDevice(device) != hipSuccess)
@@ -95,16 +94,16 @@ extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
     delete ctx;
     return DEGA_ERROR_LIBRARY_INIT;
   }
-  std::vector<DivEntry> tab;
+  std::vector<uint32_t> tab;
   build_div_table(tab);
-  if (hipMalloc((void **)&ctx->div_table, tab.size() * sizeof(DivEntry)) != hipSuccess)
+  if (hipMalloc((void **)&ctx->div_magic, tab.size() * sizeof(uint32_t)) != hipSuccess)
   {
     delete ctx;
     return DEGA_ERROR_MEMORY;
   }
-  if (hipMemcpy(ctx->div_table, tab.data(), tab.size() * sizeof(DivEntry), hipMemcpyHostToDevice) != hipSuccess)
+  if (hipMemcpy(ctx->div_magic, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
   {
-    hipFree(ctx->div_table);
+    hipFree(ctx->div_magic);
     delete ctx;
     return DEGA_ERROR_LIBRARY_INIT;
   }
@@ -120,7 +119,7 @@ extern "C" void dega_hip_destroy(dega_hip_ctx *ctx)
   for (int k = 0; k < 2; k++)
     for (hipEvent_t e : ctx->ev[k])
       hipEventDestroy(e);
-  hipFree(ctx->div_table);
+  hipFree(ctx->div_magic);
   delete ctx;
 }
 
@@ -232,7 +231,7 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   a.cap = cap;
   a.out_bits = out_bits;
   a.err = err;
-  a.div_table = ctx->div_table;
+  a.div_magic = ctx->div_magic;
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {

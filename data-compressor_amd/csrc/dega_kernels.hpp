@@ -51,11 +51,11 @@ struct EncodeArgs
   size_t cap;       // bytes per channel, multiple of 4
   uint64_t *out_bits;
   int32_t *err;
-  const DivEntry *div_table; // DIV_TABLE_SIZE entries, global memory
+  const uint32_t *div_magic; // DIV_TABLE_SIZE division magics (dega_lane.hpp), global memory
 };
 
 template <bool ADAPTIVE>
-DG_DEV void load_div_table(DivEntry *tab, const DivEntry *gtab)
+DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
 {
   if (ADAPTIVE)
   {
@@ -70,10 +70,10 @@ DG_DEV void load_div_table(DivEntry *tab, const DivEntry *gtab)
 template <bool ADAPTIVE>
 __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 {
-  __shared__ DivEntry tab[ADAPTIVE ? DIV_TABLE_SIZE : 4];
+  __shared__ uint32_t tab[ADAPTIVE ? DIV_TABLE_SIZE : 4]; // 64 KiB
   __shared__ uint32_t ring[WAVES * ENC_RING * 64];
 
-  load_div_table<ADAPTIVE>(tab, a.div_table);
+  load_div_table<ADAPTIVE>(tab, a.div_magic);
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -124,13 +124,25 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     const bool has = q.wr != q.rd;
     if (!wave_any(has))
       break; // all rows consumed and every queue drained
+    const bool fast = wave_all(!has || enc.fast_ok()); // wave uniform: the unrolled branch-free word, or bit by bit
     if (has)
     {
       const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
       q.rd++;
-#pragma unroll
-      for (uint32_t i = 0; i < 32; i++)
-        enc.encode_bit((word >> (31u - i)) & 1u, tab);
+      bool done = false;
+      if (fast)
+      {
+        const BacEncoder<ADAPTIVE> checkpoint = enc;
+        done = enc.encode_word_fast(word, tab);
+        if (!done)
+          enc = checkpoint; // a carry ran past the held-back word (33+ pending bits): redo exactly
+      }
+      if (!done)
+      {
+#pragma unroll 1
+        for (uint32_t i = 0; i < 32; i++)
+          enc.encode_bit((word >> (31u - i)) & 1u, tab);
+      }
     }
   }
 
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     for (uint32_t i = 0; i < tail; i++)
       enc.encode_bit((word >> (31u - i)) & 1u, tab);
     a.out_bits[c] = enc.finish(tab);
-    a.err[c] = lane_err != OK ? lane_err : enc.sink.err;
+    a.err[c] = lane_err != OK ? lane_err : enc.err;
   }
 }
 

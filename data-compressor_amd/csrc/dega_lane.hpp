@@ -8,14 +8,25 @@
 // Reference behaviour reproduced here (paths relative to the reference's DataCompressor/):
 //   diff  DCLib/src/diff.c:9-37      seg  DCLib/src/seg.c:11-94      bac  DCLib/src/bac.c:39-263
 //   bit order DCIOLib/src/bit_file_buffer.c:220-248,297-308 (MSB first; 32-bit words therefore big-endian)
+//
+// Cost model this code is written against (profiles/r01_ubench_issue_cost.txt, measured on MI355X): a wave issues one
+// instruction every ~4 cycles whatever it is (VALU add, 32x32 multiply, 64-bit shift, SALU, LDS), and more waves per
+// SIMD do not raise the VALU rate -- so time = instruction count, and a divergent `if` costs its exec-mask SALU
+// bookkeeping on every pass.  Hence: an unrolled, branch-free 32-symbol fast path with selects, every rare event
+// (model halving, MPS/LPS swap, a carry running past the word kept back for it, slab nearly full) moved to a
+// per-word precondition or a checkpoint-and-redo, and a general bit-at-a-time slow path that handles everything.
 #pragma once
 
 #include <stdint.h>
 
 #if defined(DEGA_SIM)
 #define DG_DEV inline
+#define DG_MATERIALISE(x) ((void)0)
 #else
 #define DG_DEV __device__ __forceinline__
+// the value must be in its register here: stops hipcc from sinking a load down to its first use (where its latency
+// would sit in the per-symbol dependency chain)
+#define DG_MATERIALISE(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace dg
@@ -28,15 +39,6 @@ constexpr int32_t ERR_MEMORY = -6;
 
 constexpr uint32_t MAX_FREQUENCY = 16383; // bac.c:27
 constexpr uint32_t DIV_TABLE_SIZE = 16384;
-
-// Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic) >> shift  with
-// magic = ceil(2^(30+L) / t), L = ceil(log2 t), shift = L - 2  (error term < 2^-L <= 1/t, so the floor is exact).
-// This replaces the two 64-bit divisions per symbol of bac.c:110-111; numerators there are R*cum <= 2^16 * 2^13.
-struct DivEntry
-{
-  uint32_t magic;
-  uint32_t shift;
-};
 
 DG_DEV uint32_t clz32(uint32_t x) // x != 0
 {
@@ -52,233 +54,283 @@ DG_DEV uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
+DG_DEV uint32_t mul24(uint32_t a, uint32_t b) // both < 2^24
+{
+#if defined(DEGA_SIM)
+  return a * b;
+#else
+  return (uint32_t)__umul24(a, b);
+#endif
+}
+
 DG_DEV uint32_t bswap32(uint32_t x)
 {
   return __builtin_bswap32(x);
 }
 
-DG_DEV uint32_t div_by_total(uint32_t n, const DivEntry &e)
+DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // mask is all ones or all zeros: v_bfi_b32
 {
-  return mulhi32(n, e.magic) >> e.shift;
+  return (if_set & mask) | (if_clear & ~mask);
+}
+
+// Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic[t]) >> shift(t)  with
+// magic = ceil(2^(30+L) / t), L = ceil(log2 t), shift = L - 2: the error term n*(magic*t - 2^(30+L)) / (t * 2^(30+L)) is
+// below 2^-L <= 1/t, so the floor cannot move.  This replaces the two 64-bit divisions per symbol of bac.c:110-111
+// (numerators there are range * cum <= 2^16 * 2^13).  The table holds the magics (64 KiB); the shift comes from t.
+DG_DEV uint32_t div_shift(uint32_t t)
+{
+  return 30u - clz32(t - 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Output side of the arithmetic coder: a 64-bit carry-propagating accumulator instead of bit-plus-follow.
+// The encoder.
 //
-// The reference emits a bit per E1/E2 shift and defers E3 ("underflow") shifts in a counter that is resolved by the
-// next emitted bit (bac.c:93-105,127-132).  The emitted stream is exactly the binary expansion of the running sum of
-// the `start` increments, each added at the current window position; an E3 shift provisionally emits 0 then 1s and
-// a later carry out of the window flips them -- which is what a plain multi-word addition does.  So the lane keeps
-//   W = [ cnt already-shifted-out bits | 16-bit window | zeros ]   (left aligned in 64 bits)
-// adds the increment at the window's position, and lets carries ripple.  A carry out of W (needs >= 17 consecutive
-// one bits in flight) is fixed up in the words already stored, which this lane wrote itself.
+// Interval state (bac.c:83-139) in a form whose renormalisation is branch free:
+//   A = start << 16,   B = (65535 - end) << 16   (low 16 bits always zero)
+// so that range - 1 = ~(A + B) >> 16, the E1/E2 shift count is clz(~(A ^ B)) (length of the common prefix of start and
+// end), and the number of E3 steps that follow is the run of ones below bit 31 of (A & B) after that shift.  After an
+// E3 step the reference clears the top bit of both; here it is left set in both ("spurious" bit 31): every use either
+// shifts it out or cancels it (A + B mod 2^32, A ^ B).
+//
+// Output side: a carry-propagating accumulator instead of bit-plus-follow.  The reference emits a bit per E1/E2 shift
+// and defers E3 shifts in a counter resolved by the next emitted bit (bac.c:93-105,127-132).  The stream it produces is
+// exactly the binary expansion of the running sum of the `start` increments, each added at the current window
+// position: an E3 shift provisionally emits 0 then 1s and a later carry out of the window flips them, which is what a
+// multi-word addition does.  So the lane keeps
+//   W    = [ finished bits | 16-bit window | zeros ], left aligned in 64 bits; wsh = bit index of the window's LSB
+//   prev = the last completed 32-bit word, held back from memory so that it can still absorb carries out of W
+//   pc   = carries that left W since prev was taken
+// and stores prev + pc when the next word completes.  A carry running even past prev (33+ pending bits) is rippled
+// into the words already stored, which this lane wrote itself.
+//
+// Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
+// frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
-struct BitSink
+template <bool ADAPTIVE>
+struct BacEncoder
 {
-  uint64_t W;          // accumulator, see above
-  uint32_t cnt;        // number of finished bits at the top of W (0..31 between symbols)
-  uint32_t pos;        // 32-bit words already stored
-  uint32_t cap_words;  // capacity of the channel's slab in words
-  uint32_t *dst;       // channel's slab
+  uint32_t A, B;
+  uint32_t c1, tot, mps;
+  uint64_t W;
+  uint32_t wsh;
+  uint32_t prev, pc, pos; // pos = words completed so far; prev is word pos-1
+  uint32_t cap_words;
+  uint32_t *dst;
   int32_t err;
 
   DG_DEV void init(uint32_t *dst_, uint32_t cap_words_)
   {
+    A = 0; // bac.c:86-91
+    B = 0;
+    c1 = 2; // bac.c:39-52
+    tot = 3;
+    mps = 0;
     W = 0;
-    cnt = 0;
+    wsh = 48;
+    prev = 0;
+    pc = 0;
     pos = 0;
     cap_words = cap_words_;
     dst = dst_;
     err = OK;
   }
 
-  DG_DEV void carry_into_stored_words()
+  // ---- general path: one bit at a time, every special case handled in place --------------------------------------
+
+  DG_DEV void put_word(uint32_t index, uint32_t word)
   {
-    uint32_t p = pos;
-    while (p > 0)
+    if (index < cap_words)
+      dst[index] = bswap32(word); // MSB-first bit order => big-endian words
+    else if (err == OK)
+      err = ERR_MEMORY;
+  }
+
+  DG_DEV void ripple_carry_from(uint32_t count) // add one to the big number formed by words [0, count)
+  {
+    while (count > 0)
     {
-      --p;
-      if (p < cap_words)
+      --count;
+      if (count < cap_words)
       {
-        const uint32_t w = bswap32(dst[p]) + 1u;
-        dst[p] = bswap32(w);
+        const uint32_t w = bswap32(dst[count]) + 1u;
+        dst[count] = bswap32(w);
         if (w != 0)
           break;
       }
     }
   }
 
-  // add `inc` (< 2^17) at the window: window LSB sits at bit (48 - cnt)
+  DG_DEV void store_prev()
+  {
+    if (pos > 0)
+    {
+      const uint32_t sum = prev + pc;
+      if (sum < pc)
+        ripple_carry_from(pos - 1);
+      put_word(pos - 1, sum);
+    }
+  }
+
   DG_DEV void add_at_window(uint32_t inc)
   {
-    const uint64_t add = (uint64_t)inc << (48u - cnt);
+    const uint64_t add = (uint64_t)inc << wsh;
     const uint64_t nw = W + add;
-    if (nw < add)
-      carry_into_stored_words();
+    pc += nw < add ? 1u : 0u;
     W = nw;
   }
 
-  DG_DEV void store_word(uint32_t word)
+  DG_DEV void advance(uint32_t n) // the window moved n bits to the right: n more finished bits
   {
-    if (pos < cap_words)
-      dst[pos] = bswap32(word); // MSB-first bit order => big-endian words
-    else if (err == OK)
-      err = ERR_MEMORY;
-    pos++;
-  }
-
-  // the window moved n bits to the right: n more finished bits
-  DG_DEV void advance(uint32_t n)
-  {
-    cnt += n;
-    if (cnt >= 32)
+    wsh -= n;
+    if (wsh <= 16)
     {
-      store_word((uint32_t)(W >> 32));
+      store_prev();
+      prev = (uint32_t)(W >> 32);
+      pc = 0;
+      pos++;
       W <<= 32;
-      cnt -= 32;
+      wsh += 32;
     }
   }
 
-  // total stream length in bits after `extra` final bits have been accounted for with advance()
-  DG_DEV uint64_t finish()
-  {
-    const uint64_t total = (uint64_t)pos * 32u + cnt;
-    if (cnt > 0)
-    {
-      const uint32_t word = (uint32_t)(W >> 32) & ~(0xFFFFFFFFu >> cnt); // zero padding (bit_file_buffer.c:310-320)
-      store_word(word);
-    }
-    return total;
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Adaptive model, binary case of bac.c:39-81.  Index 1 holds the more frequent bit value (`mps`), index 2 the other,
-// index 3 is EOF with frequency 1 forever.  cum[0] = f1+f2+1, cum[1] = f2+1, cum[2] = 1, cum[3] = 0.
-// ---------------------------------------------------------------------------------------------------------------------
-struct Model
-{
-  uint32_t f1, f2, mps;
-
-  DG_DEV void init() // bac.c:39-52
-  {
-    f1 = 1;
-    f2 = 1;
-    mps = 0;
-  }
-
-  DG_DEV uint32_t total() const
-  {
-    return f1 + f2 + 1;
-  }
-
-  DG_DEV void update(bool lps) // bac.c:54-81
-  {
-    if (f1 + f2 + 1 == MAX_FREQUENCY) // :57-67 halve, rounding up; EOF stays 1
-    {
-      f1 = (f1 + 1) >> 1;
-      f2 = (f2 + 1) >> 1;
-    }
-    if (lps)
-    {
-      if (f2 == f1) // :68-77 the coded symbol moves to index 1
-      {
-        mps ^= 1u;
-        f1++;
-      }
-      else
-        f2++;
-    }
-    else
-      f1++;
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Interval state of the coder (bac.c:83-139) in a form whose renormalisation is branch free:
-//   A = start << 16,   B = (65535 - end) << 16   (low 16 bits always zero)
-// so that  range - 1 = ~(A + B) >> 16,  the E1/E2 shift count is clz(~(A ^ B))  (length of the common prefix of start
-// and end), and the number of E3 steps that follow is the run of ones below bit 31 of (A & B).  After an E3 step the
-// reference clears the top bit of both; here it is left set in both ("spurious" bit 31): every use either shifts it
-// out or cancels it (A + B mod 2^32, A ^ B), which saves two instructions per symbol.
-// ---------------------------------------------------------------------------------------------------------------------
-struct Interval
-{
-  uint32_t A, B;
-
-  DG_DEV void init() // bac.c:86-91
-  {
-    A = 0;
-    B = 0;
-  }
-
-  DG_DEV uint32_t range() const // 1..65536
-  {
-    return ((~(A + B)) >> 16) + 1u;
-  }
-
-  // returns the number of window shifts (E1/E2 + E3)
-  DG_DEV uint32_t renormalise() // bac.c:112-137
+  DG_DEV uint32_t renormalise() // bac.c:112-137; returns the number of window shifts (E1/E2 + E3)
   {
     const uint32_t k = clz32(~(A ^ B)); // <= 16: the low halves differ by construction
-    A <<= k;
-    B <<= k;
-    const uint32_t v = (A & B) | 0x80000000u;
-    const uint32_t j = clz32(~v) - 1u; // run of ones below bit 31; ~v != 0 because the low 16 bits of v are zero
-    A <<= j;
-    B <<= j;
-    return k + j;
-  }
-};
-
-template <bool ADAPTIVE>
-struct BacEncoder
-{
-  Interval iv;
-  Model m;
-  BitSink sink;
-
-  DG_DEV void init(uint32_t *dst, uint32_t cap_words)
-  {
-    iv.init();
-    m.init();
-    sink.init(dst, cap_words);
+    const uint32_t v = ((A & B) << k) | 0x80000000u;
+    const uint32_t n = k + clz32(~v) - 1u; // run of ones below bit 31; ~v != 0 because the low 16 bits of v are zero
+    A <<= n;
+    B <<= n;
+    return n;
   }
 
-  // One data bit: EncodeSymbol + UpdateModel (bac.c:156-161).  tab = division table indexed by cum[0].
-  DG_DEV void encode_bit(uint32_t bit, const DivEntry *tab)
+  DG_DEV void update_model(bool lps) // bac.c:54-81
   {
-    const DivEntry de = tab[m.total()];
-    const uint32_t R = iv.range();
-    const uint32_t x1 = div_by_total(R * (m.f2 + 1u), de); // range * cum[1] / cum[0]
-    const bool lps = bit != m.mps;
-    uint32_t inc = x1;
+    if (tot == MAX_FREQUENCY) // :57-67 halve, rounding up; EOF stays 1
+    {
+      const uint32_t f1 = (tot - c1 + 1u) >> 1;
+      const uint32_t f2 = c1 >> 1; // (f2 + 1) / 2 with f2 = c1 - 1
+      c1 = f2 + 1u;
+      tot = f1 + f2 + 1u;
+    }
     if (lps)
     {
-      // index 2: end = start + x1 - 1, start += range * cum[2] / cum[0] with cum[2] = 1   (bac.c:110-111)
-      iv.B = 0u - (iv.A + (x1 << 16));
-      inc = div_by_total(R, de);
+      if (c1 - 1u == tot - c1) // :68-77 f2 == f1: the coded symbol moves to index 1, then f1++
+        mps ^= 1u;
+      else
+        c1++;
     }
-    // index 1: end unchanged (cum[0]/cum[0]), start += x1
-    iv.A += inc << 16;
-    sink.add_at_window(inc);
-    sink.advance(iv.renormalise());
+    tot++;
+  }
+
+  DG_DEV void encode_bit(uint32_t bit, const uint32_t *magic) // EncodeSymbol + UpdateModel (bac.c:156-161)
+  {
+    const uint32_t M = magic[tot];
+    const uint32_t sh = div_shift(tot);
+    const uint32_t R = ((~(A + B)) >> 16) + 1u;
+    const uint32_t x1 = mulhi32(R * c1, M) >> sh; // range * cum[1] / cum[0]
+    const bool lps = bit != mps;
+    uint32_t inc = x1; // index 1: end unchanged, start += x1
+    if (lps)
+    {
+      B = 0u - (A + (x1 << 16)); // index 2: end = start + x1 - 1 ...
+      inc = mulhi32(R, M) >> sh; // ... start += range * cum[2] / cum[0], cum[2] = 1   (bac.c:110-111)
+    }
+    A += inc << 16;
+    add_at_window(inc);
+    advance(renormalise());
     if (ADAPTIVE)
-      m.update(lps);
+      update_model(lps);
   }
 
   // EOF symbol + FinishEncoding (bac.c:163-164, 141-145); returns the exact stream length in bits
-  DG_DEV uint64_t finish(const DivEntry *tab)
+  DG_DEV uint64_t finish(const uint32_t *magic)
   {
-    const DivEntry de = tab[m.total()];
-    const uint32_t x2 = div_by_total(iv.range(), de); // index 3: cum[2] = 1, cum[3] = 0
-    iv.B = 0u - (iv.A + (x2 << 16));                   // end = start + x2 - 1, start unchanged
-    sink.advance(iv.renormalise());
+    const uint32_t R = ((~(A + B)) >> 16) + 1u;
+    const uint32_t x2 = mulhi32(R, magic[tot]) >> div_shift(tot); // index 3: cum[2] = 1, cum[3] = 0
+    B = 0u - (A + (x2 << 16));                                     // end = start + x2 - 1, start unchanged
+    advance(renormalise());
     // "pending++ ; emit (start < Q ? 0 : 1) and the pending inverse bits" == round the window up to the next multiple
-    // of Q and emit its top two bits (carries resolve any pending run).
-    sink.add_at_window(0x4000u);
-    sink.advance(2);
-    return sink.finish();
+    // of Q and emit its top two bits (the carry resolves any pending run).
+    add_at_window(0x4000u);
+    advance(2);
+    store_prev();
+    const uint32_t cnt = 48u - wsh;
+    if (cnt > 0)
+      put_word(pos, (uint32_t)(W >> 32) & ~(0xFFFFFFFFu >> cnt)); // zero padding (bit_file_buffer.c:310-320)
+    return (uint64_t)pos * 32u + cnt;
+  }
+
+  // ---- fast path: 32 symbols, branch free except for the word store ------------------------------------------------
+
+  // Preconditions for encode_word_fast on this lane (evaluated once per word):
+  DG_DEV bool fast_ok() const
+  {
+    bool ok = pos >= 1 && pos + 17u <= cap_words; // prev exists; room for the most a word can emit (32 * 16 bits)
+    if (ADAPTIVE)
+    {
+      ok = ok && tot + 32u <= MAX_FREQUENCY;                  // no halving during these 32 updates
+      ok = ok && tot + 1u >= 2u * c1 + 32u;                   // f1 - f2 >= 32: no MPS/LPS swap can occur
+      ok = ok && clz32(tot - 1u) == clz32(tot + 30u);         // one division shift for the whole word
+    }
+    return ok;
+  }
+
+  // Codes the 32 bits of `word`.  Returns false if a carry ran past `prev` (the caller restores its checkpoint and
+  // redoes the word with encode_bit).
+  DG_DEV bool encode_word_fast(uint32_t word, const uint32_t *magic)
+  {
+    const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
+    const uint32_t *const mg = magic + tot;
+    const uint32_t sh = div_shift(tot);
+    uint32_t *sp = dst + (pos - 1u);
+    uint32_t ovf = 0;
+    uint32_t Mg[32]; // the 32 division magics of this word (cum[0] = tot .. tot+31), fetched from LDS up front
+#pragma unroll
+    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+      Mg[i] = mg[i];
+#pragma unroll
+    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+      DG_MATERIALISE(Mg[i]);
+#pragma unroll
+    for (uint32_t i = 0; i < 32; i++)
+    {
+      const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
+      const uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for an LPS
+      const uint32_t Rm1 = (~(A + B)) >> 16;
+      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
+      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
+      const uint32_t inc = select32(lm, x2, x1);
+      B = select32(lm, 0u - (A + (x1 << 16)), B);
+      A += inc << 16;
+      if (ADAPTIVE)
+        c1 -= lm; // f2++ for an LPS; tot is implicit (mg[i])
+      // output accumulator
+      const uint64_t add = (uint64_t)inc << wsh;
+      const uint64_t nw = W + add;
+      pc += nw < add ? 1u : 0u;
+      W = nw;
+      // renormalise
+      const uint32_t k = clz32(~(A ^ B));
+      const uint32_t v = ((A & B) << k) | 0x80000000u;
+      const uint32_t n = k + clz32(~v) - 1u;
+      A <<= n;
+      B <<= n;
+      wsh -= n;
+      if (wsh <= 16) // a word completed: store the one held back, hold this one back
+      {
+        const uint32_t sum = prev + pc;
+        ovf |= sum < pc ? 1u : 0u;
+        *sp++ = bswap32(sum);
+        prev = (uint32_t)(W >> 32);
+        pc = 0;
+        W <<= 32;
+        wsh += 32;
+      }
+    }
+    pos = (uint32_t)(sp - dst) + 1u;
+    if (ADAPTIVE)
+      tot += 32u;
+    return ovf == 0;
   }
 };
 

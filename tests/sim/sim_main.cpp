@@ -10,24 +10,23 @@
 
 using namespace dg;
 
-static std::vector<DivEntry> make_table()
+static std::vector<uint32_t> make_table()
 {
-  std::vector<DivEntry> tab(DIV_TABLE_SIZE, DivEntry{0u, 0u});
+  std::vector<uint32_t> tab(DIV_TABLE_SIZE, 0u);
   for (uint32_t t = 3; t < DIV_TABLE_SIZE; t++)
   {
     uint32_t L = 0;
     while ((1u << L) < t)
       L++;
     const unsigned __int128 num = (unsigned __int128)1 << (30 + L);
-    tab[t].magic = (uint32_t)((num + t - 1) / t);
-    tab[t].shift = L - 2;
+    tab[t] = (uint32_t)((num + t - 1) / t);
   }
   return tab;
 }
 
 extern "C" __attribute__((visibility("default"))) int sim_encode(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
 {
-  static const std::vector<DivEntry> tab = make_table();
+  static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data()};
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   if (adaptive)
@@ -56,4 +55,93 @@ extern "C" __attribute__((visibility("default"))) int sim_synth(int32_t *x, size
   SynthArgs a{x, C, T, ld, seed, c0, S};
   sim::launch(dega_synth_kernel, dim3((unsigned)((C + BLOCK - 1) / BLOCK)), dim3(BLOCK), a);
   return 0;
+}
+
+// ---- direct test of the encoder's fast word path against its bit-at-a-time path, on random (and nasty) states -----
+#include <random>
+#include <string.h>
+
+template <bool ADAPTIVE>
+static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_taken)
+{
+  static const std::vector<uint32_t> tab = make_table();
+  std::mt19937_64 rng(seed);
+  int bad = 0;
+  for (int r = 0; r < rounds; r++)
+  {
+    std::vector<uint32_t> buf_a(64), buf_b(64);
+    const bool nasty = (rng() % 4) == 0;
+    for (int i = 0; i < 64; i++)
+      buf_a[i] = buf_b[i] = (nasty && (rng() % 4)) ? 0xFFFFFFFFu : (uint32_t)rng();
+    BacEncoder<ADAPTIVE> e;
+    e.init(buf_a.data(), 64);
+    // a normalised interval: start < H <= end and not (start >= Q and end < 3Q)
+    uint32_t s, en;
+    do
+    {
+      s = (uint32_t)(rng() % 0x8000u);
+      en = 0x8000u + (uint32_t)(rng() % 0x8000u);
+    } while (s >= 0x4000u && en < 0xC000u);
+    e.A = s << 16;
+    e.B = (65535u - en) << 16;
+    if (rng() & 1)
+    {
+      e.A |= 0x80000000u; // the "spurious" top bits left by an E3 step
+      e.B |= 0x80000000u;
+    }
+    if (ADAPTIVE)
+    {
+      do
+      {
+        e.tot = 3 + (uint32_t)(rng() % 16380u);
+        e.c1 = 1 + (uint32_t)(rng() % ((e.tot + 1) / 2));
+      } while (e.c1 < 2 && e.tot < 3);
+      e.mps = (uint32_t)(rng() & 1);
+    }
+    const uint32_t cnt = (uint32_t)(rng() % 32u);
+    e.wsh = 48 - cnt;
+    e.W = nasty ? ~(uint64_t)0 : rng();
+    e.W &= ~(((uint64_t)1 << e.wsh) - 1);                         // nothing below the window
+    e.W = (e.W & ~((uint64_t)0xFFFF << e.wsh)) | ((uint64_t)s << e.wsh); // the window holds start (or start + 2^15)
+    e.prev = nasty ? 0xFFFFFFFFu - (uint32_t)(rng() % 2) : (uint32_t)rng();
+    e.pc = (uint32_t)(rng() % 3);
+    e.pos = 1 + (uint32_t)(rng() % 40u);
+    BacEncoder<ADAPTIVE> f = e;
+    f.dst = buf_b.data();
+    const uint32_t word = (rng() % 3) ? (uint32_t)rng() : (uint32_t)(rng() & rng() & rng());
+    // (a) bit at a time
+    for (uint32_t i = 0; i < 32; i++)
+      e.encode_bit((word >> (31u - i)) & 1u, tab.data());
+    // (b) fast word with checkpoint / redo, as the kernel does
+    if (f.fast_ok())
+    {
+      (*fast_taken)++;
+      const BacEncoder<ADAPTIVE> ck = f;
+      if (!f.encode_word_fast(word, tab.data()))
+      {
+        (*redo_taken)++;
+        f = ck;
+        for (uint32_t i = 0; i < 32; i++)
+          f.encode_bit((word >> (31u - i)) & 1u, tab.data());
+      }
+    }
+    else
+      for (uint32_t i = 0; i < 32; i++)
+        f.encode_bit((word >> (31u - i)) & 1u, tab.data());
+    // flush both the same way and compare everything observable
+    e.store_prev();
+    f.store_prev();
+    const bool same = e.A == f.A && e.B == f.B && e.c1 == f.c1 && e.tot == f.tot && e.mps == f.mps && e.W == f.W && e.wsh == f.wsh &&
+                      e.prev == f.prev && e.pc == f.pc && e.pos == f.pos && e.err == f.err && buf_a == buf_b;
+    if (!same)
+      bad++;
+  }
+  return bad;
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_fast_vs_slow(uint64_t seed, int rounds, int adaptive, int *fast_taken, int *redo_taken)
+{
+  *fast_taken = 0;
+  *redo_taken = 0;
+  return adaptive ? fast_vs_slow<true>(seed, rounds, fast_taken, redo_taken) : fast_vs_slow<false>(seed, rounds, fast_taken, redo_taken);
 }

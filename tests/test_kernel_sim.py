@@ -79,3 +79,14 @@ def test_synth_and_normalize_kernels(sim):
     back = np.zeros(vt.shape, dtype=np.float32)
     sim.sim_denormalize(xi.ctypes.data, 2, v.size, 2, 100.0, back.ctypes.data)
     assert back[:, 1].tobytes() == z["denorm_100"].tobytes()
+
+
+def test_fast_word_path_equals_bit_path_on_random_and_nasty_states(sim):
+    """BacEncoder::encode_word_fast (+ checkpoint/redo) against encode_bit on random encoder states, including all-ones
+    accumulators and held-back words that overflow when a carry arrives (the 33+-pending-bits case)."""
+    sim.sim_fast_vs_slow.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for ad in (1, 0):
+        fast, redo = C.c_int(), C.c_int()
+        bad = sim.sim_fast_vs_slow(2024, 60000, ad, C.byref(fast), C.byref(redo))
+        assert bad == 0
+        assert fast.value > 50000 and redo.value > 1000  # both the fast path and the redo path were exercised
