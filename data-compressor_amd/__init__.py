@@ -17,7 +17,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdega_hip.so")
+LIB_PATH = os.environ.get("DEGA_HIP_LIB", os.path.join(HERE, "libdega_hip.so"))  # override: diagnostic builds only
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "dega_hip.h")
 
 OK = 0

@@ -35,6 +35,15 @@ DG_DEV bool wave_all(bool p)
 }
 #endif
 
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+// diagnostic build: per-wave cycle totals per section of the encode loop (s_memtime), dumped over out_bits[] / err[]
+#define DG_STAMP_DECL uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DG_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_sum[k] += now_ - stamp_t0; stamp_cnt[k]++; stamp_t0 = now_; } while (0)
+#else
+#define DG_STAMP_DECL
+#define DG_STAMP(k)
+#endif
+
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
 
@@ -71,7 +80,9 @@ template <bool ADAPTIVE>
 __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 {
   __shared__ uint32_t tab[ADAPTIVE ? DIV_TABLE_SIZE : 4]; // 64 KiB
-  __shared__ uint32_t ring[WAVES * ENC_RING * 64];
+  __shared__ uint32_t ring[WAVES * ENC_RING * 64];   // seg bits waiting to be coded, per lane
+  __shared__ uint32_t oring[WAVES * ENC_ORING * 64]; // coded words waiting to be stored, per lane
+  __shared__ uint32_t xrows[WAVES * ENC_ROWS * 64];  // the next input rows, per lane
 
   load_div_table<ADAPTIVE>(tab, a.div_magic);
 
@@ -83,25 +94,40 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   const int32_t *const col = a.x + (live ? c : 0);
 
   BacEncoder<ADAPTIVE> enc;
-  enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u);
+  enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u,
+           &oring[wave * ENC_ORING * 64 + lane]);
   BitQueue q;
   q.init();
   uint32_t last = 0; // diff.c:11
   int32_t lane_err = OK;
 
-  size_t t = 0; // rows consumed, wave uniform
-  uint32_t xr[ENC_ROWS];
+  // Input rows travel  HBM -> registers (loads issued right after the fill step of every iteration) -> LDS (parked
+  // there after the code step, by which time the loads have long landed) -> the next fill.  The loads and the parking
+  // are unconditional (a step without a fill re-reads the same rows, from L2), so that on every path nothing is
+  // pending at the loop's back edge: hipcc's wait-count pass is path insensitive and would otherwise put a vmcnt(0)
+  // in the fill -- behind the drain's stores, which retire in order with the loads (measured: 26 % of all cycles).
+  uint32_t *const rows_col = &xrows[wave * ENC_ROWS * 64 + lane];
+  size_t t = 0; // rows consumed by fills, wave uniform; LDS always holds rows [t, t + ENC_ROWS)
+  const size_t t_last = a.T > 0 ? a.T - 1 : 0;
 #pragma unroll
   for (uint32_t i = 0; i < ENC_ROWS; i++)
-    xr[i] = (live && i < a.T) ? (uint32_t)col[(size_t)i * a.ld] : 0u;
+    rows_col[i * 64u] = (live && a.T > 0) ? (uint32_t)col[(i < a.T ? i : t_last) * a.ld] : 0u;
 
+  DG_STAMP_DECL;
   for (;;)
   {
+    DG_STAMP(7);
+    // ---- phase F: the same ENC_ROWS rows for every lane ----------------------------------------------------------
     const bool room = (q.wr - q.rd) + ENC_FILL_WORDS <= ENC_RING;
-    if (t < a.T && wave_all(room))
+    const bool fill = t < a.T && wave_all(room);
+    DG_STAMP(0);
+    if (fill)
     {
-      // ---- phase F: the same ENC_ROWS rows for every lane --------------------------------------------------------
       const size_t left = a.T - t;
+      uint32_t xr[ENC_ROWS];
+#pragma unroll
+      for (uint32_t i = 0; i < ENC_ROWS; i++)
+        xr[i] = rows_col[i * 64u];
 #pragma unroll
       for (uint32_t i = 0; i < ENC_ROWS; i++)
       {
@@ -114,36 +140,79 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
         }
       }
       t += left < ENC_ROWS ? left : ENC_ROWS;
-      // next batch's rows: in flight while phase C runs
+      DG_STAMP(1);
+    }
+    uint32_t xt[ENC_ROWS]; // rows [t, t + ENC_ROWS), clamped to the last row: in flight while phase C runs
 #pragma unroll
-      for (uint32_t i = 0; i < ENC_ROWS; i++)
-        xr[i] = (live && t + i < a.T) ? (uint32_t)col[(t + i) * a.ld] : 0u;
-      continue;
+    for (uint32_t i = 0; i < ENC_ROWS; i++)
+    {
+      const size_t row = t + i < a.T ? t + i : t_last;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 2)
+      xt[i] = (uint32_t)(row * 7u + lane); // diagnostic build: no input loads
+#else
+      xt[i] = live ? (uint32_t)col[row * a.ld] : 0u;
+#endif
     }
     // ---- phase C: one queued word (32 symbols) for every lane that has one ---------------------------------------
     const bool has = q.wr != q.rd;
-    if (!wave_any(has))
+    const bool any_has = wave_any(has);
+    if (!any_has && !fill)
       break; // all rows consumed and every queue drained
-    const bool fast = wave_all(!has || enc.fast_ok()); // wave uniform: the unrolled branch-free word, or bit by bit
-    if (has)
+    DG_STAMP(2);
+    if (any_has)
     {
-      const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
-      q.rd++;
-      bool done = false;
-      if (fast)
+      const bool fast = wave_all(!has || enc.fast_ok()); // wave uniform: the unrolled branch-free word, or bit by bit
+      if (has)
       {
-        const BacEncoder<ADAPTIVE> checkpoint = enc;
-        done = enc.encode_word_fast(word, tab);
+        const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
+        q.rd++;
+        bool done = false;
+        if (fast)
+        {
+          const BacEncoder<ADAPTIVE> checkpoint = enc;
+          done = enc.encode_word_fast(word, tab);
+          if (!done)
+            enc = checkpoint; // a carry ran past the held-back word (33+ pending bits): redo exactly
+        }
         if (!done)
-          enc = checkpoint; // a carry ran past the held-back word (33+ pending bits): redo exactly
-      }
-      if (!done)
-      {
+        {
 #pragma unroll 1
-        for (uint32_t i = 0; i < 32; i++)
-          enc.encode_bit((word >> (31u - i)) & 1u, tab);
+          for (uint32_t i = 0; i < 32; i++)
+            enc.encode_bit((word >> (31u - i)) & 1u, tab);
+        }
       }
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+      if (fast)
+        DG_STAMP(3);
+      else
+        DG_STAMP(4);
+#endif
     }
+    // ---- park the rows loaded during this step (the compiler's vmcnt wait lands here, ahead of the drain's stores) --
+#pragma unroll
+    for (uint32_t i = 0; i < ENC_ROWS; i++)
+      rows_col[i * 64u] = xt[i];
+    DG_STAMP(5);
+    // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------
+    {
+      const uint32_t n = enc.staged;
+      const uint32_t w0 = enc.oring[0], w1 = enc.oring[64]; // nearly always 0..2 words per step: fetch both at once
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 1)
+      if (n > 100) // diagnostic build: no output stores
+        enc.put_word(enc.drained, w0 + w1);
+#else
+      if (n > 0)
+        enc.put_word(enc.drained, w0);
+      if (n > 1)
+        enc.put_word(enc.drained + 1u, w1);
+      for (uint32_t s = 2; wave_any(s < n); s++)
+        if (s < n)
+          enc.put_word(enc.drained + s, enc.oring[s * 64u]);
+#endif
+      enc.drained += n;
+      enc.staged = 0;
+    }
+    DG_STAMP(6);
   }
 
   if (live)
@@ -155,6 +224,12 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
       enc.encode_bit((word >> (31u - i)) & 1u, tab);
     a.out_bits[c] = enc.finish(tab);
     a.err[c] = lane_err != OK ? lane_err : enc.err;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+    if (lane < 8)
+      a.out_bits[c] = stamp_sum[lane];
+    else if (lane < 16)
+      a.out_bits[c] = stamp_cnt[lane - 8];
+#endif
   }
 }
 

@@ -106,6 +106,8 @@ DG_DEV uint32_t div_shift(uint32_t t)
 // Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
 // frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t ENC_ORING = 16; // staged output words per lane: the most one 32-symbol word can complete (32 * 16 bits)
+
 template <bool ADAPTIVE>
 struct BacEncoder
 {
@@ -113,12 +115,14 @@ struct BacEncoder
   uint32_t c1, tot, mps;
   uint64_t W;
   uint32_t wsh;
-  uint32_t prev, pc, pos; // pos = words completed so far; prev is word pos-1
+  uint32_t prev, pc, pos;   // pos = words completed so far; prev is word pos-1 (held back)
+  uint32_t drained, staged; // words [0, drained) are in the slab, [drained, drained + staged) in the lane's LDS column
   uint32_t cap_words;
-  uint32_t *dst;
+  uint32_t *dst;   // channel's slab (global memory)
+  uint32_t *oring; // lane's column of the LDS output ring: slot s at oring[s * 64]
   int32_t err;
 
-  DG_DEV void init(uint32_t *dst_, uint32_t cap_words_)
+  DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
   {
     A = 0; // bac.c:86-91
     B = 0;
@@ -130,8 +134,11 @@ struct BacEncoder
     prev = 0;
     pc = 0;
     pos = 0;
+    drained = 0;
+    staged = 0;
     cap_words = cap_words_;
     dst = dst_;
+    oring = oring_;
     err = OK;
   }
 
@@ -145,8 +152,25 @@ struct BacEncoder
       err = ERR_MEMORY;
   }
 
+  DG_DEV void drain_lane() // LDS column -> slab, this lane only (the kernel normally drains whole waves in lockstep)
+  {
+    for (uint32_t s = 0; s < staged; s++)
+      put_word(drained + s, oring[s * 64u]);
+    drained += staged;
+    staged = 0;
+  }
+
+  DG_DEV void push_word(uint32_t word)
+  {
+    if (staged == ENC_ORING)
+      drain_lane();
+    oring[staged * 64u] = word;
+    staged++;
+  }
+
   DG_DEV void ripple_carry_from(uint32_t count) // add one to the big number formed by words [0, count)
   {
+    drain_lane();
     while (count > 0)
     {
       --count;
@@ -167,7 +191,7 @@ struct BacEncoder
       const uint32_t sum = prev + pc;
       if (sum < pc)
         ripple_carry_from(pos - 1);
-      put_word(pos - 1, sum);
+      push_word(sum);
     }
   }
 
@@ -254,18 +278,19 @@ struct BacEncoder
     add_at_window(0x4000u);
     advance(2);
     store_prev();
+    drain_lane();
     const uint32_t cnt = 48u - wsh;
     if (cnt > 0)
       put_word(pos, (uint32_t)(W >> 32) & ~(0xFFFFFFFFu >> cnt)); // zero padding (bit_file_buffer.c:310-320)
     return (uint64_t)pos * 32u + cnt;
   }
 
-  // ---- fast path: 32 symbols, branch free except for the word store ------------------------------------------------
+  // ---- fast path: 32 symbols, branch free except for the word hand-off ---------------------------------------------
 
   // Preconditions for encode_word_fast on this lane (evaluated once per word):
   DG_DEV bool fast_ok() const
   {
-    bool ok = pos >= 1 && pos + 17u <= cap_words; // prev exists; room for the most a word can emit (32 * 16 bits)
+    bool ok = pos >= 1 && staged == 0; // a held-back word exists; the LDS column is empty (room for 16 words)
     if (ADAPTIVE)
     {
       ok = ok && tot + 32u <= MAX_FREQUENCY;                  // no halving during these 32 updates
@@ -275,24 +300,34 @@ struct BacEncoder
     return ok;
   }
 
-  // Codes the 32 bits of `word`.  Returns false if a carry ran past `prev` (the caller restores its checkpoint and
-  // redoes the word with encode_bit).
+  // Codes the 32 bits of `word`; completed words go to the lane's LDS column (the kernel drains it afterwards).
+  // Returns false if a carry ran past `prev` (the caller restores its checkpoint and redoes the word with encode_bit).
   DG_DEV bool encode_word_fast(uint32_t word, const uint32_t *magic)
   {
     const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
     const uint32_t *const mg = magic + tot;
     const uint32_t sh = div_shift(tot);
-    uint32_t *sp = dst + (pos - 1u);
+    uint32_t *op = oring;
     uint32_t ovf = 0;
     uint32_t Mg[32]; // the 32 division magics of this word (cum[0] = tot .. tot+31), fetched from LDS up front
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
+      Mg[i] = 0x40000000u + tot * 131u + i; // diagnostic build: no table reads
+#else
       Mg[i] = mg[i];
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
       DG_MATERIALISE(Mg[i]);
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 8)
+    constexpr uint32_t NSYM = 16; // diagnostic build: half the symbols per word
+#else
+    constexpr uint32_t NSYM = 32;
+#endif
+    constexpr uint32_t FLUSH_EVERY = 4;
 #pragma unroll
-    for (uint32_t i = 0; i < 32; i++)
+    for (uint32_t i = 0; i < NSYM; i++)
     {
       const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
       const uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for an LPS
@@ -316,18 +351,27 @@ struct BacEncoder
       A <<= n;
       B <<= n;
       wsh -= n;
-      if (wsh <= 16) // a word completed: store the one held back, hold this one back
+      // Word hand-off, checked every FLUSH_EVERY symbols only: between checks the accumulator may hold up to 47
+      // finished bits (wsh >= 1).  A burst of more than 16 + (32 - cnt) bits inside one group would push the window
+      // out of W; wsh then wraps and the word is redone from the checkpoint (needs ~4+ bits per symbol: rare).
+      if ((i % FLUSH_EVERY) == FLUSH_EVERY - 1)
       {
-        const uint32_t sum = prev + pc;
-        ovf |= sum < pc ? 1u : 0u;
-        *sp++ = bswap32(sum);
-        prev = (uint32_t)(W >> 32);
-        pc = 0;
-        W <<= 32;
-        wsh += 32;
+        ovf |= wsh > 48u ? 1u : 0u;
+        if (wsh <= 16) // a word completed: hand over the one held back, hold this one back
+        {
+          const uint32_t sum = prev + pc;
+          ovf |= sum < pc ? 1u : 0u;
+          *op = sum;
+          op += 64;
+          prev = (uint32_t)(W >> 32);
+          pc = 0;
+          W <<= 32;
+          wsh += 32;
+        }
       }
     }
-    pos = (uint32_t)(sp - dst) + 1u;
+    staged = (uint32_t)(op - oring) / 64u;
+    pos += staged;
     if (ADAPTIVE)
       tot += 32u;
     return ovf == 0;

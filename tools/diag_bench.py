@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Ablation timing of the encode kernel: times libdega_hip.so and the DEGA_DIAG builds (csrc/Makefile `diag`) on the
+same synthetic batch in one process each.  Diagnostic builds produce wrong streams by construction."""
+import os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    from __graft_entry__ import load_package
+    dca = load_package()
+    ctx = dca.Context(0)
+    C_, T = int(sys.argv[2]), int(sys.argv[3])
+    x = ctx.synth(C_, T)
+    cap = 4 * ((T * 4 + 67) // 4)
+    out = torch.zeros((C_, cap), dtype=torch.uint8, device="cuda"); bits = torch.zeros(C_, dtype=torch.int64, device="cuda"); err = torch.zeros(C_, dtype=torch.int32, device="cuda")
+    ctx.encode(x, cap=cap, out=out, bits=bits, err=err); torch.cuda.synchronize()
+    ctx.profile(True)
+    for _ in range(3):
+        ctx.encode(x, cap=cap, out=out, bits=bits, err=err)
+    torch.cuda.synchronize()
+    n, ms = ctx.profile_read(0)
+    res = {"lib": os.path.basename(dca.LIB_PATH), "kernel_ms": round(ms, 4), "bits_per_sample": round(float(bits.sum()) / (C_ * T), 3)}
+    if "diag32" in dca.LIB_PATH:
+        b = bits.cpu().numpy().reshape(-1, 64)
+        names = ["ballot_room", "fill", "loads+ballot_has", "fast_word", "slow_word", "park", "drain", "loop_top"]
+        res["cycles_per_wave"] = {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}
+        res["total_cycles"] = int(b[:, :8].sum(axis=1).mean())
+    print(json.dumps(res))
+else:
+    C_, T = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("65536", "8640")
+    libs = [os.path.join(ROOT, "data-compressor_amd", "libdega_hip.so")] + sorted(
+        os.path.join(ROOT, "tools", "diag", f) for f in os.listdir(os.path.join(ROOT, "tools", "diag")) if f.endswith(".so"))
+    for lib in libs:
+        env = dict(os.environ, DEGA_HIP_LIB=lib)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child", C_, T], env=env)
