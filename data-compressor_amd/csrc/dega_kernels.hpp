@@ -44,6 +44,26 @@ DG_DEV bool wave_all(bool p)
 #define DG_STAMP(k)
 #endif
 
+#if !defined(DEGA_SIM)
+// One dword per lane from global memory straight into LDS (LDS-DMA): lane l's dword lands at lds_row[l].
+// lds_row must be wave uniform.  Completion is NOT tracked by hipcc: wait with wait_vector_memory() before reading.
+DG_DEV void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t /*lane*/)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_row, 4, 0, 0);
+}
+DG_DEV void wait_vector_memory()
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#else
+inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
+{
+  lds_row[lane] = (uint32_t)*src;
+}
+inline void wait_vector_memory() {}
+#endif
+
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
 
@@ -79,10 +99,14 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
 template <bool ADAPTIVE>
 __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 {
-  __shared__ uint32_t tab[ADAPTIVE ? DIV_TABLE_SIZE : 4]; // 64 KiB
-  __shared__ uint32_t ring[WAVES * ENC_RING * 64];   // seg bits waiting to be coded, per lane
-  __shared__ uint32_t oring[WAVES * ENC_ORING * 64]; // coded words waiting to be stored, per lane
-  __shared__ uint32_t xrows[WAVES * ENC_ROWS * 64];  // the next input rows, per lane
+  // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
+  // access with a vmcnt(0) wait):  division magics (64 KiB) | seg-bit rings | coded-word rings | input rows
+  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
+  __shared__ uint32_t lds[TAB_WORDS + WAVES * (ENC_RING + ENC_ORING + ENC_ROWS) * 64];
+  uint32_t *const tab = lds;
+  uint32_t *const ring = tab + TAB_WORDS;              // seg bits waiting to be coded, per lane
+  uint32_t *const oring = ring + WAVES * ENC_RING * 64;  // coded words waiting to be stored, per lane
+  uint32_t *const xrows = oring + WAVES * ENC_ORING * 64; // the next input rows, per lane
 
   load_div_table<ADAPTIVE>(tab, a.div_magic);
 
@@ -101,22 +125,81 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   uint32_t last = 0; // diff.c:11
   int32_t lane_err = OK;
 
-  // Input rows travel  HBM -> registers (loads issued right after the fill step of every iteration) -> LDS (parked
-  // there after the code step, by which time the loads have long landed) -> the next fill.  The loads and the parking
-  // are unconditional (a step without a fill re-reads the same rows, from L2), so that on every path nothing is
-  // pending at the loop's back edge: hipcc's wait-count pass is path insensitive and would otherwise put a vmcnt(0)
-  // in the fill -- behind the drain's stores, which retire in order with the loads (measured: 26 % of all cycles).
-  uint32_t *const rows_col = &xrows[wave * ENC_ROWS * 64 + lane];
-  size_t t = 0; // rows consumed by fills, wave uniform; LDS always holds rows [t, t + ENC_ROWS)
+  // Input rows travel HBM -> LDS directly (LDS-DMA, `global_load_lds_dword`: one 256-byte row segment per wave
+  // instruction, no VGPR destination) and are read from LDS by the next fill.  All vector-memory traffic of an
+  // iteration -- the row DMA and the drain's stores -- is issued at the END of the iteration; the single vmcnt wait
+  // sits right after the NEXT iteration's code step, ~6000 cycles later, when everything has long retired.  (vmcnt
+  // retires in order: with register loads hipcc placed vmcnt(0) waits right behind the drain's stores -- 26 % of all
+  // cycles -- and copied freshly loaded registers at the loop's back edge.)
+  uint32_t *const rows_wave = &xrows[wave * ENC_ROWS * 64]; // wave uniform
+  const uint32_t *const rows_col = rows_wave + lane;
+  size_t t = 0; // rows consumed by fills, wave uniform; after the wait LDS holds rows [t, t + ENC_ROWS)
   const size_t t_last = a.T > 0 ? a.T - 1 : 0;
+  const int32_t *const last_row = a.x + t_last * a.ld;
+  const uint32_t col_idx = live ? (uint32_t)c : 0u; // C <= 2^32 columns
+
+  auto issue_rows = [&](size_t t0) // rows [t0, t0 + ENC_ROWS), clamped to the last row
+  {
+    const int32_t *rowp = a.x + t0 * a.ld; // wave uniform; the lane adds its 32-bit column index
 #pragma unroll
-  for (uint32_t i = 0; i < ENC_ROWS; i++)
-    rows_col[i * 64u] = (live && a.T > 0) ? (uint32_t)col[(i < a.T ? i : t_last) * a.ld] : 0u;
+    for (uint32_t i = 0; i < ENC_ROWS; i++)
+    {
+      const int32_t *const r = t0 + i < a.T ? rowp : last_row;
+      if (live)
+        dma_row_to_lds(r + col_idx, rows_wave + i * 64u, lane);
+      rowp += a.ld;
+    }
+  };
+  if (a.T > 0)
+    issue_rows(0);
 
   DG_STAMP_DECL;
   for (;;)
   {
     DG_STAMP(7);
+    // ---- phase C: one queued word (32 symbols) for every lane that has one ---------------------------------------
+    const bool has = q.wr != q.rd;
+    const bool any_has = wave_any(has);
+    DG_STAMP(2);
+    if (any_has)
+    {
+      // wave uniform choice: the fast word (no model event possible in it), the general word (halving / swap / shift
+      // change handled branch free), or bit by bit (first word of a channel, leftovers in the LDS column)
+      const bool fast = wave_all(!has || enc.fast_ok());
+      const bool general = ADAPTIVE && !fast && wave_all(!has || enc.general_ok());
+      if (has)
+      {
+        const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
+        q.rd++;
+        bool done = false;
+        if (fast || general)
+        {
+          const BacEncoder<ADAPTIVE> checkpoint = enc;
+          if (fast)
+            done = enc.encode_word_fast(word, tab);
+          else if constexpr (ADAPTIVE)
+            done = enc.encode_word_general(word, tab);
+          if (!done)
+            enc = checkpoint; // a carry ran past the held-back word, or > 48 bits piled up: redo exactly
+        }
+        if (!done)
+        {
+#pragma unroll 1
+          for (uint32_t i = 0; i < 32; i++)
+            enc.encode_bit((word >> (31u - i)) & 1u, tab);
+        }
+      }
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+      if (fast)
+        DG_STAMP(3);
+      else
+        DG_STAMP(4);
+      (void)general;
+#endif
+    }
+    // ---- everything issued at the end of the previous iteration has landed by now ----------------------------------
+    wait_vector_memory();
+    DG_STAMP(5);
     // ---- phase F: the same ENC_ROWS rows for every lane ----------------------------------------------------------
     const bool room = (q.wr - q.rd) + ENC_FILL_WORDS <= ENC_RING;
     const bool fill = t < a.T && wave_all(room);
@@ -131,68 +214,39 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 #pragma unroll
       for (uint32_t i = 0; i < ENC_ROWS; i++)
       {
-        if (i < left && live)
+        if (i < left) // wave uniform
         {
-          const SegWord s = diff_seg(xr[i], last);
-          if (!s.ok && lane_err == OK)
-            lane_err = ERR_INVALID_VALUE;
-          q.put_codeword<ENC_RING>(s, ring_col);
+          // short codewords (|delta| < 2^15, the steady state) take the branch-free route; a wave holding a wide one
+          // (first sample of a channel, a jump) goes through the general three-piece writer
+          uint32_t last_try = last;
+          bool ok, wide;
+          const uint32_t w = diff_seg_short(xr[i], last_try, ok, wide);
+          if (!wave_any(wide && live))
+          {
+            if (live)
+            {
+              last = last_try;
+              if (!ok && lane_err == OK)
+                lane_err = ERR_INVALID_VALUE;
+              q.put_short<ENC_RING>(w, ring_col);
+            }
+          }
+          else if (live)
+          {
+            const SegWord s = diff_seg(xr[i], last);
+            if (!s.ok && lane_err == OK)
+              lane_err = ERR_INVALID_VALUE;
+            q.put_codeword<ENC_RING>(s, ring_col);
+          }
         }
       }
       t += left < ENC_ROWS ? left : ENC_ROWS;
       DG_STAMP(1);
+      if (t < a.T)
+        issue_rows(t); // in flight during the next code step
     }
-    uint32_t xt[ENC_ROWS]; // rows [t, t + ENC_ROWS), clamped to the last row: in flight while phase C runs
-#pragma unroll
-    for (uint32_t i = 0; i < ENC_ROWS; i++)
-    {
-      const size_t row = t + i < a.T ? t + i : t_last;
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 2)
-      xt[i] = (uint32_t)(row * 7u + lane); // diagnostic build: no input loads
-#else
-      xt[i] = live ? (uint32_t)col[row * a.ld] : 0u;
-#endif
-    }
-    // ---- phase C: one queued word (32 symbols) for every lane that has one ---------------------------------------
-    const bool has = q.wr != q.rd;
-    const bool any_has = wave_any(has);
-    if (!any_has && !fill)
+    else if (!any_has)
       break; // all rows consumed and every queue drained
-    DG_STAMP(2);
-    if (any_has)
-    {
-      const bool fast = wave_all(!has || enc.fast_ok()); // wave uniform: the unrolled branch-free word, or bit by bit
-      if (has)
-      {
-        const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
-        q.rd++;
-        bool done = false;
-        if (fast)
-        {
-          const BacEncoder<ADAPTIVE> checkpoint = enc;
-          done = enc.encode_word_fast(word, tab);
-          if (!done)
-            enc = checkpoint; // a carry ran past the held-back word (33+ pending bits): redo exactly
-        }
-        if (!done)
-        {
-#pragma unroll 1
-          for (uint32_t i = 0; i < 32; i++)
-            enc.encode_bit((word >> (31u - i)) & 1u, tab);
-        }
-      }
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-      if (fast)
-        DG_STAMP(3);
-      else
-        DG_STAMP(4);
-#endif
-    }
-    // ---- park the rows loaded during this step (the compiler's vmcnt wait lands here, ahead of the drain's stores) --
-#pragma unroll
-    for (uint32_t i = 0; i < ENC_ROWS; i++)
-      rows_col[i * 64u] = xt[i];
-    DG_STAMP(5);
     // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------
     {
       const uint32_t n = enc.staged;

@@ -376,6 +376,79 @@ struct BacEncoder
       tot += 32u;
     return ovf == 0;
   }
+
+  // ---- general word path: 32 symbols, still branch free, with the whole model update of bac.c:54-81 --------------
+  // Used for the words during which some lane of the wave halves its frequencies, may swap MPS/LPS, or crosses a
+  // power of two in cum[0] (the division shift changes).  Costs ~1.5x the fast path instead of ~3x for encode_bit.
+  DG_DEV bool general_ok() const
+  {
+    return pos >= 1 && staged == 0;
+  }
+
+  DG_DEV bool encode_word_general(uint32_t word, const uint32_t *magic)
+  {
+    static_assert(ADAPTIVE, "the static model never needs the general path");
+    uint32_t *op = oring;
+    uint32_t ovf = 0;
+    uint32_t mm = 0u - mps;                       // all ones when the MPS is the bit value 1
+    uint32_t M = magic[tot];
+    constexpr uint32_t FLUSH_EVERY = 4;
+#pragma unroll
+    for (uint32_t i = 0; i < 32; i++)
+    {
+      // (1) the part of the model update that does not depend on this symbol: halving, next cum[0]; fetch its magic now
+      const bool halve = tot == MAX_FREQUENCY;
+      const uint32_t c1h = (c1 >> 1) + 1u;                        // (f2 + 1) / 2 + 1
+      const uint32_t toth = ((tot - c1 + 1u) >> 1) + c1h;         // (f1 + 1) / 2 + (f2 + 1) / 2 + 1
+      const uint32_t c1u = halve ? c1h : c1;                      // counts as UpdateModel sees them after :57-67
+      const uint32_t totu = halve ? toth : tot;
+      const uint32_t Mnext = magic[totu + 1u];
+      // (2) code the symbol with the counts as they are (same arithmetic as the fast path)
+      const uint32_t sh = div_shift(tot);
+      const uint32_t lm = (uint32_t)((int32_t)(word << i) >> 31) ^ mm; // all ones for an LPS
+      const uint32_t Rm1 = (~(A + B)) >> 16;
+      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
+      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
+      const uint32_t inc = select32(lm, x2, x1);
+      B = select32(lm, 0u - (A + (x1 << 16)), B);
+      A += inc << 16;
+      const uint64_t add = (uint64_t)inc << wsh;
+      const uint64_t nw = W + add;
+      pc += nw < add ? 1u : 0u;
+      W = nw;
+      const uint32_t k = clz32(~(A ^ B));
+      const uint32_t v = ((A & B) << k) | 0x80000000u;
+      const uint32_t n = k + clz32(~v) - 1u;
+      A <<= n;
+      B <<= n;
+      wsh -= n;
+      // (3) the symbol-dependent part of the update (:68-80): an LPS either swaps roles (f2 == f1) or counts up
+      const uint32_t tie = (c1u - 1u == totu - c1u) ? 0xFFFFFFFFu : 0u;
+      mm ^= lm & tie;
+      c1 = c1u - (lm & ~tie);
+      tot = totu + 1u;
+      M = Mnext;
+      if ((i % FLUSH_EVERY) == FLUSH_EVERY - 1)
+      {
+        ovf |= wsh > 48u ? 1u : 0u;
+        if (wsh <= 16)
+        {
+          const uint32_t sum = prev + pc;
+          ovf |= sum < pc ? 1u : 0u;
+          *op = sum;
+          op += 64;
+          prev = (uint32_t)(W >> 32);
+          pc = 0;
+          W <<= 32;
+          wsh += 32;
+        }
+      }
+    }
+    mps = mm & 1u;
+    staged = (uint32_t)(op - oring) / 64u;
+    pos += staged;
+    return ovf == 0;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -410,6 +483,19 @@ DG_DEV SegWord diff_seg(uint32_t u, uint32_t &last)
   return r;
 }
 
+// diff + seg for the common case, branch free: returns w (the codeword's value; its length is 2*floor(log2 w) + 1 bits).
+// w = zigzag(-v) + 1 with v = x - last:  v > 0 -> 2v,  v <= 0 -> 2|v| + 1  (seg.c:25-28 + the "+1" of seg.c:13).
+// Only valid when the result fits 16 bits (codeword <= 31 bits); `wide` says when it does not (or v = INT32_MIN).
+DG_DEV uint32_t diff_seg_short(uint32_t u, uint32_t &last, bool &ok, bool &wide)
+{
+  const uint32_t nv = last - u;                                    // -v, low 32 bits
+  ok = (u >= last) == ((int32_t)nv <= 0);                          // diff.c:17-18: the true difference fits int32
+  last = u;
+  const uint32_t w = ((nv << 1) ^ (uint32_t)((int32_t)nv >> 31)) + 1u;
+  wide = (w >> 16) != 0u || nv == 0x80000000u;
+  return w;
+}
+
 // Per-lane bit queue feeding the coder: bits are appended MSB first, whole 32-bit words go to the lane's column of an
 // LDS ring (slot-major: ring[slot * 64 + lane], so a wave's access is always conflict free).
 struct BitQueue
@@ -438,6 +524,13 @@ struct BitQueue
       wr++;
       cnt -= 32;
     }
+  }
+
+  // a codeword of value w < 2^16: 2p+1 <= 31 bits, one piece (its leading zeros are the prefix, seg.c:18-19)
+  template <uint32_t RING>
+  DG_DEV void put_short(uint32_t w, uint32_t *ring_col)
+  {
+    put<RING>(w, 63u - 2u * clz32(w), ring_col);
   }
 
   template <uint32_t RING>

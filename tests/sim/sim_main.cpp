@@ -94,8 +94,11 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_ta
     {
       do
       {
-        e.tot = 3 + (uint32_t)(rng() % 16380u);
-        e.c1 = 1 + (uint32_t)(rng() % ((e.tot + 1) / 2));
+        const unsigned kind = (unsigned)(rng() % 4);
+        e.tot = kind == 0 ? 16383u - (uint32_t)(rng() % 40u) : kind == 1 ? 3u + (uint32_t)(rng() % 70u) : 3u + (uint32_t)(rng() % 16380u);
+        e.c1 = 2 + (uint32_t)(rng() % ((e.tot - 1) / 2));                 // 1 <= f2 <= f1
+        if (kind == 1 || (rng() % 8) == 0)
+          e.c1 = (e.tot + 1) / 2 - (uint32_t)(rng() % 2 ? 0 : (e.tot > 8 ? rng() % 3 : 0)); // f2 == f1 or nearly: swaps
       } while (e.c1 < 2 && e.tot < 3);
       e.mps = (uint32_t)(rng() & 1);
     }
@@ -116,11 +119,17 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_ta
     for (uint32_t i = 0; i < 32; i++)
       e.encode_bit((word >> (31u - i)) & 1u, tab.data());
     // (b) fast word with checkpoint / redo, as the kernel does
-    if (f.fast_ok())
+    const bool use_general = ADAPTIVE && (r & 1) && f.general_ok(); // odd rounds: the general word path
+    if (use_general || f.fast_ok())
     {
       (*fast_taken)++;
       const BacEncoder<ADAPTIVE> ck = f;
-      if (!f.encode_word_fast(word, tab.data()))
+      bool done;
+      if constexpr (ADAPTIVE)
+        done = use_general ? f.encode_word_general(word, tab.data()) : f.encode_word_fast(word, tab.data());
+      else
+        done = f.encode_word_fast(word, tab.data());
+      if (!done)
       {
         (*redo_taken)++;
         f = ck;

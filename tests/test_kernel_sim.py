@@ -89,4 +89,4 @@ def test_fast_word_path_equals_bit_path_on_random_and_nasty_states(sim):
         fast, redo = C.c_int(), C.c_int()
         bad = sim.sim_fast_vs_slow(2024, 60000, ad, C.byref(fast), C.byref(redo))
         assert bad == 0
-        assert fast.value > 50000 and redo.value > 1000  # both the fast path and the redo path were exercised
+        assert fast.value > 30000 and redo.value > 1000  # both the fast path and the redo path were exercised
