@@ -67,8 +67,9 @@ inline void wait_vector_memory() {}
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
 
-constexpr uint32_t ENC_RING = 16;                               // queued words per lane (LDS: 4 KiB per wave)
-constexpr uint32_t ENC_ROWS = 4;                                // rows per fill batch
+constexpr uint32_t ENC_RING = 32;                               // queued words per lane (LDS: 4 KiB per wave)
+constexpr uint32_t ENC_ROWS = 8;                                // rows per fill batch
+constexpr uint32_t ENC_DRAIN_EVERY = 4;                            // code steps between output drains
 constexpr uint32_t ENC_FILL_WORDS = (31 + 65 * ENC_ROWS) / 32;  // most words a batch can add (65-bit worst-case codewords)
 static_assert(ENC_FILL_WORDS < ENC_RING, "ring too small");
 
@@ -153,6 +154,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   if (a.T > 0)
     issue_rows(0);
 
+  uint32_t iter = 0;
   DG_STAMP_DECL;
   for (;;)
   {
@@ -213,30 +215,44 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
         xr[i] = rows_col[i * 64u];
 #pragma unroll
       for (uint32_t i = 0; i < ENC_ROWS; i++)
+        DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
+      // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
+      uint32_t w[ENC_ROWS];
+      uint32_t last_try = last;
+      bool all_ok = true, any_wide = false;
+#pragma unroll
+      for (uint32_t i = 0; i < ENC_ROWS; i++)
       {
-        if (i < left) // wave uniform
+        bool ok, wide;
+        w[i] = diff_seg_short(xr[i], last_try, ok, wide);
+        all_ok = all_ok && ok;
+        any_wide = any_wide || wide;
+      }
+      if (left >= ENC_ROWS && !wave_any(any_wide && live))
+      {
+        // the steady state: a full batch of short codewords, straight-line appends
+        if (live)
         {
-          // short codewords (|delta| < 2^15, the steady state) take the branch-free route; a wave holding a wide one
-          // (first sample of a channel, a jump) goes through the general three-piece writer
-          uint32_t last_try = last;
-          bool ok, wide;
-          const uint32_t w = diff_seg_short(xr[i], last_try, ok, wide);
-          if (!wave_any(wide && live))
+          last = last_try;
+          if (!all_ok && lane_err == OK)
+            lane_err = ERR_INVALID_VALUE;
+#pragma unroll
+          for (uint32_t i = 0; i < ENC_ROWS; i++)
+            q.put_short<ENC_RING>(w[i], ring_col);
+        }
+      }
+      else if (live)
+      {
+        // first samples of a channel, jumps, the last partial batch: the general three-piece writer, row by row
+#pragma unroll
+        for (uint32_t i = 0; i < ENC_ROWS; i++)
+        {
+          if (i < left)
           {
-            if (live)
-            {
-              last = last_try;
-              if (!ok && lane_err == OK)
-                lane_err = ERR_INVALID_VALUE;
-              q.put_short<ENC_RING>(w, ring_col);
-            }
-          }
-          else if (live)
-          {
-            const SegWord s = diff_seg(xr[i], last);
-            if (!s.ok && lane_err == OK)
+            const SegWord sw = diff_seg(xr[i], last);
+            if (!sw.ok && lane_err == OK)
               lane_err = ERR_INVALID_VALUE;
-            q.put_codeword<ENC_RING>(s, ring_col);
+            q.put_codeword<ENC_RING>(sw, ring_col);
           }
         }
       }
@@ -247,24 +263,36 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     }
     else if (!any_has)
       break; // all rows consumed and every queue drained
-    // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------
+    // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
+    // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
+    iter++;
+    if ((iter % ENC_DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ENC_ORING))
     {
-      const uint32_t n = enc.staged;
-      const uint32_t w0 = enc.oring[0], w1 = enc.oring[64]; // nearly always 0..2 words per step: fetch both at once
+      uint32_t base = 0; // first staged slot not yet stored
+      while (wave_any(enc.staged - base >= 4u))
+      {
+        if (enc.staged - base >= 4u)
+        {
+          const uint32_t *const sl = enc.oring + base * 64u;
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 1)
-      if (n > 100) // diagnostic build: no output stores
-        enc.put_word(enc.drained, w0 + w1);
-#else
-      if (n > 0)
-        enc.put_word(enc.drained, w0);
-      if (n > 1)
-        enc.put_word(enc.drained + 1u, w1);
-      for (uint32_t s = 2; wave_any(s < n); s++)
-        if (s < n)
-          enc.put_word(enc.drained + s, enc.oring[s * 64u]);
+          if (sl[0] == 0x12345u) // diagnostic build: no output stores
 #endif
-      enc.drained += n;
-      enc.staged = 0;
+            enc.put_group(enc.drained + base, sl[0], sl[64], sl[128], sl[192]);
+          base += 4;
+        }
+      }
+      // move the 0..3 left-over words to the front of the column
+      const uint32_t rest = enc.staged - base;
+      const uint32_t *const sl = enc.oring + base * 64u;
+      const uint32_t r0 = sl[0], r1 = sl[64], r2 = sl[128];
+      if (base > 0 && rest > 0)
+      {
+        enc.oring[0] = r0;
+        enc.oring[64] = r1;
+        enc.oring[128] = r2;
+      }
+      enc.drained += base;
+      enc.staged = rest;
     }
     DG_STAMP(6);
   }

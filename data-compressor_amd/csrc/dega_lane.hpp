@@ -68,9 +68,27 @@ DG_DEV uint32_t bswap32(uint32_t x)
   return __builtin_bswap32(x);
 }
 
-DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // mask is all ones or all zeros: v_bfi_b32
+DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // mask is all ones or all zeros
 {
+#if defined(DEGA_SIM)
   return (if_set & mask) | (if_clear & ~mask);
+#else
+  uint32_t r; // one v_bfi_b32; left to itself hipcc rebuilds the select from a compare, two v_cndmask and and/or
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(if_set), "v"(if_clear));
+  return r;
+#endif
+}
+
+// (~x) >> 16 in one instruction (SDWA: NOT of the high word, written zero-extended)
+DG_DEV uint32_t not_hi16(uint32_t x)
+{
+#if defined(DEGA_SIM)
+  return (~x) >> 16;
+#else
+  uint32_t r;
+  asm("v_not_b32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(x));
+  return r;
+#endif
 }
 
 // Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic[t]) >> shift(t)  with
@@ -106,7 +124,8 @@ DG_DEV uint32_t div_shift(uint32_t t)
 // Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
 // frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t ENC_ORING = 16; // staged output words per lane: the most one 32-symbol word can complete (32 * 16 bits)
+constexpr uint32_t ENC_WORD_MAX_OUT = 16; // the most one 32-symbol word can complete (32 * 16 bits)
+constexpr uint32_t ENC_ORING = 32;        // staged output words per lane; word paths need ENC_WORD_MAX_OUT free slots
 
 template <bool ADAPTIVE>
 struct BacEncoder
@@ -158,6 +177,31 @@ struct BacEncoder
       put_word(drained + s, oring[s * 64u]);
     drained += staged;
     staged = 0;
+  }
+
+  // Four staged words (slots s .. s+3) as one 16-byte store: scattered stores cost per instruction, not per byte.
+  DG_DEV void put_group(uint32_t index, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+  {
+    if (index + 4u <= cap_words)
+    {
+#if defined(DEGA_SIM)
+      dst[index] = bswap32(w0);
+      dst[index + 1] = bswap32(w1);
+      dst[index + 2] = bswap32(w2);
+      dst[index + 3] = bswap32(w3);
+#else
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+      u32x4 v = {bswap32(w0), bswap32(w1), bswap32(w2), bswap32(w3)};
+      *reinterpret_cast<u32x4 *>(dst + index) = v;
+#endif
+    }
+    else
+    {
+      put_word(index, w0);
+      put_word(index + 1u, w1);
+      put_word(index + 2u, w2);
+      put_word(index + 3u, w3);
+    }
   }
 
   DG_DEV void push_word(uint32_t word)
@@ -290,7 +334,7 @@ struct BacEncoder
   // Preconditions for encode_word_fast on this lane (evaluated once per word):
   DG_DEV bool fast_ok() const
   {
-    bool ok = pos >= 1 && staged == 0; // a held-back word exists; the LDS column is empty (room for 16 words)
+    bool ok = pos >= 1 && staged + ENC_WORD_MAX_OUT <= ENC_ORING; // a held-back word exists; room in the LDS column
     if (ADAPTIVE)
     {
       ok = ok && tot + 32u <= MAX_FREQUENCY;                  // no halving during these 32 updates
@@ -307,7 +351,8 @@ struct BacEncoder
     const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
     const uint32_t *const mg = magic + tot;
     const uint32_t sh = div_shift(tot);
-    uint32_t *op = oring;
+    uint32_t *const op0 = oring + staged * 64u;
+    uint32_t *op = op0;
     uint32_t ovf = 0;
     uint32_t Mg[32]; // the 32 division magics of this word (cum[0] = tot .. tot+31), fetched from LDS up front
 #pragma unroll
@@ -331,7 +376,7 @@ struct BacEncoder
     {
       const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
       const uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for an LPS
-      const uint32_t Rm1 = (~(A + B)) >> 16;
+      const uint32_t Rm1 = not_hi16(A + B);
       const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
       const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
       const uint32_t inc = select32(lm, x2, x1);
@@ -370,8 +415,9 @@ struct BacEncoder
         }
       }
     }
-    staged = (uint32_t)(op - oring) / 64u;
-    pos += staged;
+    const uint32_t made = (uint32_t)(op - op0) / 64u;
+    staged += made;
+    pos += made;
     if (ADAPTIVE)
       tot += 32u;
     return ovf == 0;
@@ -382,13 +428,14 @@ struct BacEncoder
   // power of two in cum[0] (the division shift changes).  Costs ~1.5x the fast path instead of ~3x for encode_bit.
   DG_DEV bool general_ok() const
   {
-    return pos >= 1 && staged == 0;
+    return pos >= 1 && staged + ENC_WORD_MAX_OUT <= ENC_ORING;
   }
 
   DG_DEV bool encode_word_general(uint32_t word, const uint32_t *magic)
   {
     static_assert(ADAPTIVE, "the static model never needs the general path");
-    uint32_t *op = oring;
+    uint32_t *const op0 = oring + staged * 64u;
+    uint32_t *op = op0;
     uint32_t ovf = 0;
     uint32_t mm = 0u - mps;                       // all ones when the MPS is the bit value 1
     uint32_t M = magic[tot];
@@ -406,7 +453,7 @@ struct BacEncoder
       // (2) code the symbol with the counts as they are (same arithmetic as the fast path)
       const uint32_t sh = div_shift(tot);
       const uint32_t lm = (uint32_t)((int32_t)(word << i) >> 31) ^ mm; // all ones for an LPS
-      const uint32_t Rm1 = (~(A + B)) >> 16;
+      const uint32_t Rm1 = not_hi16(A + B);
       const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
       const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
       const uint32_t inc = select32(lm, x2, x1);
@@ -445,8 +492,9 @@ struct BacEncoder
       }
     }
     mps = mm & 1u;
-    staged = (uint32_t)(op - oring) / 64u;
-    pos += staged;
+    const uint32_t made = (uint32_t)(op - op0) / 64u;
+    staged += made;
+    pos += made;
     return ovf == 0;
   }
 };
