@@ -248,11 +248,33 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
 extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                    int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
 {
-  (void)in; (void)in_bits; (void)adaptive; (void)x_tc; (void)err; (void)stream;
   int ret;
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
     return ret;
-  return fail(ctx, DEGA_ERROR_LIBRARY_CALL, "decode kernel not built yet", hipSuccess);
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DecodeArgs a;
+  a.in = in;
+  a.cap = cap;
+  a.in_bits = in_bits;
+  a.C = C;
+  a.T = T;
+  a.ld = ld;
+  a.x = x_tc;
+  a.err = err;
+  a.div_magic = ctx->div_magic;
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 1, s);
+    if (adaptive)
+      hipLaunchKernelGGL(dega_decode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
+    else
+      hipLaunchKernelGGL(dega_decode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
 }
 
 static dim3 rowsplit_grid(size_t C, size_t T)

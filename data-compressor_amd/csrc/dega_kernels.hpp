@@ -315,6 +315,250 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   }
 }
 
+// =====================================================================================================================
+// Decode (bac -> seg -> prefix sum fused).  Mirror image of the encoder's structure:
+//   phase C ("code", word lockstep)   every lane that has input staged and room for 32 more decoded bits decodes 32
+//                                     symbols -> one word of seg bits into its column of an LDS ring.
+//   phase S ("samples")               lanes parse as many complete exp-Golomb codewords as they hold, add them up
+//                                     (diff.c:32-35) and park the samples in their column of an LDS sample ring.
+//   phase W ("write", row lockstep)   rows that every lane has produced are stored, one coalesced 256-byte segment per
+//                                     wave and row.
+//   phase R ("refill")                every few steps each lane with room fetches the next 4 words of its stream
+//                                     (LDS-DMA into a staging row; copied to the lane's own ring slots after the wait).
+// =====================================================================================================================
+constexpr uint32_t DEC_IRING = 16; // staged stream words per lane
+constexpr uint32_t DEC_BRING = 8;  // decoded seg-bit words per lane
+constexpr uint32_t DEC_SRING = 16; // decoded samples per lane
+constexpr uint32_t DEC_REFILL_EVERY = 4;
+
+struct DecodeArgs
+{
+  const uint8_t *in; // [C][cap]
+  size_t cap;
+  const uint64_t *in_bits;
+  size_t C, T, ld;
+  int32_t *x; // [T][ld]
+  int32_t *err;
+  const uint32_t *div_magic;
+};
+
+template <bool ADAPTIVE>
+__global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
+{
+  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
+  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + DEC_BRING + DEC_SRING) * 64;
+  __shared__ uint32_t lds[TAB_WORDS + WAVES * PER_WAVE];
+  uint32_t *const tab = lds;
+  load_div_table<ADAPTIVE>(tab, a.div_magic);
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = c < a.C;
+  uint32_t *const wave_lds = lds + TAB_WORDS + wave * PER_WAVE;
+  uint32_t *const iring = wave_lds + lane;                               // staged stream words
+  uint32_t *const stage_wave = wave_lds + DEC_IRING * 64;                // DMA landing rows (wave uniform)
+  uint32_t *const bring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded seg bits
+  uint32_t *const sring = wave_lds + (DEC_IRING + 4 + DEC_BRING) * 64 + lane; // decoded samples
+
+  const uint32_t cap_words = (uint32_t)(a.cap / 4);
+  const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
+  const uint64_t nbits = live ? a.in_bits[c] : 0;
+  const uint32_t total_words = (uint32_t)((nbits + 31) / 32) < cap_words ? (uint32_t)((nbits + 31) / 32) : cap_words;
+  const uint64_t max_seg_bits = (uint64_t)a.T * 65u; // no valid stream of T samples decodes to more bits
+
+  StreamWindow<DEC_IRING> in;
+  in.ring_col = iring;
+  in.nbits = nbits;
+  BacDecoder<ADAPTIVE> dec;
+  dec.init();
+  SegParser<DEC_BRING> sp;
+  sp.init(bring);
+
+  uint32_t in_loaded = 0;    // stream words staged so far (a multiple of 4 until the end)
+  uint32_t requested = 0;    // words requested by the DMA in flight (0 or up to 4)
+  bool started = false;      // StartDecoding done
+  bool bac_done = !live;     // EOF symbol seen (or error)
+  bool lane_final = !live;   // nothing more will come out of this lane
+  uint32_t bw = 0;           // decoded-bit words written
+  uint32_t part = 0, part_n = 0; // partial last word being assembled by the bit-by-bit path
+  size_t t_lane = 0;         // samples produced
+  size_t rows_stored = 0;    // wave uniform
+  int32_t lane_err = OK;
+  uint32_t iter = 0;
+
+  auto request_refill = [&]() // 4 more words for every lane that has ring room for them (and stream left)
+  {
+    const uint32_t k0 = (uint32_t)(dec.bp >> 5);
+    const bool want = live && requested == 0 && in_loaded < total_words && in_loaded + 4u - k0 <= DEC_IRING;
+    if (want)
+    {
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++)
+        if (in_loaded + j < total_words)
+          dma_row_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded + j), stage_wave + j * 64u, lane);
+      requested = total_words - in_loaded < 4u ? total_words - in_loaded : 4u;
+    }
+  };
+  request_refill();
+
+  for (;;)
+  {
+    // ---- phase C ---------------------------------------------------------------------------------------------------
+    const uint32_t k0 = (uint32_t)(dec.bp >> 5);
+    const uint32_t need_words = k0 + 4u < total_words ? k0 + 4u : total_words; // words the next 32 symbols may touch
+    const bool input_ok = in_loaded >= need_words;
+    if (live && !started && input_ok)
+    {
+      dec.start(in);
+      started = true;
+    }
+    const bool can = live && started && !bac_done && input_ok && (uint64_t)bw - (sp.pos >> 5) < DEC_BRING && part_n == 0;
+    const bool can_slow = live && started && !bac_done && input_ok && (uint64_t)bw - (sp.pos >> 5) < DEC_BRING;
+    const bool any_can = wave_any(can_slow);
+    if (any_can)
+    {
+      const bool fast = wave_all(!can_slow || (can && dec.fast_ok()));
+      if (can_slow)
+      {
+        bool done = false;
+        if (fast)
+        {
+          const BacDecoder<ADAPTIVE> checkpoint = dec;
+          uint32_t bits;
+          done = dec.decode_word_fast(in, tab, bits);
+          if (done)
+          {
+            bring[(bw % DEC_BRING) * 64u] = bits;
+            bw++;
+            sp.avail += 32;
+          }
+          else
+            dec = checkpoint;
+        }
+        if (!done)
+        {
+          // bit by bit: up to 32 symbols, stops at the EOF symbol; fills the current (possibly partial) word
+#pragma unroll 1
+          for (uint32_t i = 0; i < 32 && !bac_done; i++)
+          {
+            const uint32_t r = dec.decode_bit(in, tab);
+            if (r == 2)
+            {
+              bac_done = true;
+              if (dec.bp > nbits + 14u && lane_err == OK)
+                lane_err = ERR_INVALID_FORMAT; // more than 14 phantom bits (bac.c:171-186)
+            }
+            else
+            {
+              part = (part << 1) | r;
+              part_n++;
+              sp.avail++;
+              if (part_n == 32)
+              {
+                bring[(bw % DEC_BRING) * 64u] = part;
+                bw++;
+                part = 0;
+                part_n = 0;
+              }
+            }
+          }
+          if (bac_done && part_n > 0)
+          {
+            bring[(bw % DEC_BRING) * 64u] = part << (32u - part_n);
+            bw++;
+            part_n = 0;
+          }
+          if (!bac_done && sp.avail > max_seg_bits)
+          {
+            bac_done = true; // runaway stream: cannot be T samples
+            if (lane_err == OK)
+              lane_err = ERR_INVALID_FORMAT;
+          }
+        }
+      }
+    }
+    // ---- the DMA issued at the end of the previous step has landed: move the words to the lane's own ring slots -----
+    wait_vector_memory();
+    if (requested > 0)
+    {
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++)
+        if (j < requested)
+          iring[((in_loaded + j) % DEC_IRING) * 64u] = stage_wave[j * 64u + lane];
+      in_loaded += requested;
+      requested = 0;
+    }
+    // ---- phase S: parse what is there --------------------------------------------------------------------------------
+    {
+      bool stalled = lane_final;
+      while (wave_any(!stalled))
+      {
+        if (!stalled)
+        {
+          if (t_lane - rows_stored >= DEC_SRING)
+            stalled = true; // sample ring full until rows are written
+          else
+          {
+            uint32_t sample = 0;
+            const int32_t r = sp.next(bac_done, sample);
+            if (r == 1)
+            {
+              if (t_lane >= a.T)
+              {
+                if (lane_err == OK)
+                  lane_err = ERR_INVALID_FORMAT; // more samples than the caller asked for
+                lane_final = true;
+                stalled = true;
+              }
+              else
+              {
+                sring[(t_lane % DEC_SRING) * 64u] = sample;
+                t_lane++;
+              }
+            }
+            else if (r == 0)
+              stalled = true; // needs more decoded bits
+            else
+            {
+              if (r < 0 && lane_err == OK)
+                lane_err = r;
+              if (r == 2 && t_lane != a.T && lane_err == OK)
+                lane_err = ERR_INVALID_FORMAT; // fewer samples than the caller asked for
+              lane_final = true;
+              stalled = true;
+            }
+          }
+        }
+      }
+      if (lane_err != OK)
+      {
+        lane_final = true; // a failed channel stops here; its remaining rows are written as zeros
+        bac_done = true;
+      }
+    }
+    // ---- phase W: rows every lane has ----------------------------------------------------------------------------------
+    while (rows_stored < a.T && wave_all(lane_final || t_lane > rows_stored))
+    {
+      if (live)
+        a.x[rows_stored * a.ld + c] = t_lane > rows_stored ? (int32_t)sring[(rows_stored % DEC_SRING) * 64u] : 0;
+      rows_stored++;
+    }
+    if (rows_stored >= a.T && wave_all(lane_final))
+      break;
+    // ---- phase R ------------------------------------------------------------------------------------------------------
+    iter++;
+    {
+      const uint32_t k1 = (uint32_t)(dec.bp >> 5);
+      const bool low = live && !bac_done && in_loaded < total_words && in_loaded < k1 + 8u; // < 2 words' worth of slack
+      if ((iter % DEC_REFILL_EVERY) == 0 || wave_any(low))
+        request_refill();
+    }
+  }
+  if (live)
+    a.err[c] = lane_err;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // normalize / denormalize (DCLib/src/normalize.c), elementwise, HBM bound.  Float parity rules: the
 // multiply and the +-0.5 are two separately rounded operations (no FMA), truncating convert, IEEE division.

@@ -601,3 +601,312 @@ struct BitQueue
 };
 
 } // namespace dg
+
+// =====================================================================================================================
+// Decoder side
+// =====================================================================================================================
+namespace dg
+{
+
+constexpr int32_t ERR_LIBRARY_CALL = -11;
+
+// A lane's view of its compressed stream: 32-bit big-endian words staged in the lane's column of an LDS ring
+// (slot-major, ring[(k % IRING) * 64 + lane]); bits at or beyond `nbits` read as zero (the reference tolerates up to 14
+// such phantom bits after the end of the stream, bac.c:171-186,192).
+template <uint32_t IRING>
+struct StreamWindow
+{
+  const uint32_t *ring_col; // &ring[lane]
+  uint64_t nbits;           // exact stream length
+
+  DG_DEV uint32_t word(uint32_t k) const
+  {
+    const uint64_t first = (uint64_t)k * 32u;
+    uint32_t w = bswap32(ring_col[(k % IRING) * 64u]);
+    if (first >= nbits)
+      w = 0;
+    else if (nbits - first < 32u)
+      w &= ~(0xFFFFFFFFu >> (uint32_t)(nbits - first));
+    return w;
+  }
+
+  // 32 stream bits starting at bit position pos (words k = pos/32 and k+1 must be staged)
+  DG_DEV uint32_t peek32(uint64_t pos) const
+  {
+    const uint32_t k = (uint32_t)(pos >> 5), o = (uint32_t)pos & 31u;
+    const uint32_t w0 = word(k), w1 = word(k + 1u);
+    return o ? (w0 << o) | (w1 >> (32u - o)) : w0;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Arithmetic decoder (bac.c:168-263).  Same interval representation as the encoder; instead of `value` the lane keeps
+//   D = value - start   (0 <= D < range)
+// because every renormalisation case -- E1, E2 and E3 -- then becomes the same operation: D = (D << n) | next n bits.
+// The symbol is found without the division of bac.c:209: index 1 iff D >= x1, EOF iff D < x2, with
+// x1 = range*cum[1]/cum[0] and x2 = range*cum[2]/cum[0] -- the very quantities the interval update needs anyway
+// (integer identity: v - s >= floor(R*c/t)  <=>  (v - s + 1) * t > R * c).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool ADAPTIVE>
+struct BacDecoder
+{
+  uint32_t A, B, D;
+  uint32_t c1, tot, mps;
+  uint64_t bp; // stream bits consumed so far
+
+  DG_DEV void init()
+  {
+    A = 0;
+    B = 0;
+    D = 0;
+    c1 = 2;
+    tot = 3;
+    mps = 0;
+    bp = 0;
+  }
+
+  template <uint32_t IRING>
+  DG_DEV void start(const StreamWindow<IRING> &in) // StartDecoding, bac.c:188-204: the first 16 bits
+  {
+    D = in.peek32(0) >> 16;
+    bp = 16;
+  }
+
+  DG_DEV uint32_t renormalise()
+  {
+    const uint32_t k = clz32(~(A ^ B));
+    const uint32_t v = ((A & B) << k) | 0x80000000u;
+    const uint32_t n = k + clz32(~v) - 1u;
+    A <<= n;
+    B <<= n;
+    return n;
+  }
+
+  DG_DEV void update_model(bool lps) // as BacEncoder::update_model (bac.c:54-81)
+  {
+    if (tot == MAX_FREQUENCY)
+    {
+      const uint32_t f1 = (tot - c1 + 1u) >> 1;
+      const uint32_t f2 = c1 >> 1;
+      c1 = f2 + 1u;
+      tot = f1 + f2 + 1u;
+    }
+    if (lps)
+    {
+      if (c1 - 1u == tot - c1)
+        mps ^= 1u;
+      else
+        c1++;
+    }
+    tot++;
+  }
+
+  // One symbol, everything in place (DecodeSymbol + UpdateModel, bac.c:206-242,253-261).
+  // Returns 0/1 = the decoded bit, 2 = EOF symbol.
+  template <uint32_t IRING>
+  DG_DEV uint32_t decode_bit(const StreamWindow<IRING> &in, const uint32_t *magic)
+  {
+    const uint32_t M = magic[tot];
+    const uint32_t sh = div_shift(tot);
+    const uint32_t R = ((~(A + B)) >> 16) + 1u;
+    const uint32_t x1 = mulhi32(R * c1, M) >> sh;
+    const uint32_t x2 = mulhi32(R, M) >> sh;
+    uint32_t result;
+    bool lps = false;
+    if (D >= x1) // index 1
+    {
+      A += x1 << 16;
+      D -= x1;
+      result = mps;
+    }
+    else
+    {
+      B = 0u - (A + (x1 << 16)); // end = start + x1 - 1 for index 2 ...
+      if (D >= x2)
+      {
+        A += x2 << 16;
+        D -= x2;
+        result = mps ^ 1u;
+        lps = true;
+      }
+      else
+      {
+        B = 0u - (A + (x2 << 16)); // ... and start + x2 - 1 for EOF (index 3), start unchanged
+        result = 2;
+      }
+    }
+    const uint32_t n = renormalise();
+    if (n > 0)
+    {
+      D = (D << n) | (in.peek32(bp) >> (32u - n));
+      bp += n;
+    }
+    if (ADAPTIVE && result != 2)
+      update_model(lps);
+    return result;
+  }
+
+  DG_DEV bool fast_ok() const
+  {
+    bool ok = true;
+    if (ADAPTIVE)
+    {
+      ok = ok && tot + 32u <= MAX_FREQUENCY;
+      ok = ok && tot + 1u >= 2u * c1 + 32u;
+      ok = ok && clz32(tot - 1u) == clz32(tot + 30u);
+    }
+    return ok;
+  }
+
+  // 32 symbols, branch free.  Needs the words bp/32 .. bp/32 + 3 staged.  Returns false -- the caller restores its
+  // checkpoint and goes bit by bit -- if an EOF symbol turned up, or if one group of 4 symbols consumed more than 32
+  // stream bits (the 32-bit look-ahead is rebuilt every 4 symbols), or if the word needed more than the 4 staged words.
+  template <uint32_t IRING>
+  DG_DEV bool decode_word_fast(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t &bits_out)
+  {
+    const uint32_t *const mg = magic + tot;
+    const uint32_t sh = div_shift(tot);
+    uint32_t Mg[32];
+#pragma unroll
+    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+      Mg[i] = mg[i];
+    const uint32_t k0 = (uint32_t)(bp >> 5);
+    const uint32_t w0 = in.word(k0), w1 = in.word(k0 + 1u), w2 = in.word(k0 + 2u), w3 = in.word(k0 + 3u);
+#pragma unroll
+    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+      DG_MATERIALISE(Mg[i]);
+    uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2
+    uint32_t off_group = off;
+    uint32_t ahead = off ? (w0 << off) | (w1 >> (32u - off)) : w0; // next 32 stream bits, left aligned
+    const uint32_t mm = 0u - mps;
+    uint32_t out = 0, eof = 0, bad = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 32; i++)
+    {
+      const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
+      const uint32_t Rm1 = not_hi16(A + B);
+      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
+      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
+      const uint32_t lm = (uint32_t)((int32_t)(D - x1) >> 31); // all ones unless index 1 (D, x1 < 2^17)
+      eof = (eof << 1) | (D < x2 ? 1u : 0u);
+      const uint32_t inc = select32(lm, x2, x1);
+      B = select32(lm, 0u - (A + (x1 << 16)), B);
+      A += inc << 16;
+      D -= inc;
+      out = (out << 1) | ((lm ^ mm) & 1u);
+      if (ADAPTIVE)
+        c1 -= lm;
+      const uint32_t k = clz32(~(A ^ B));
+      const uint32_t v = ((A & B) << k) | 0x80000000u;
+      const uint32_t n = k + clz32(~v) - 1u;
+      A <<= n;
+      B <<= n;
+      const uint64_t da = (((uint64_t)D << 32) | ahead) << n; // D takes the next n bits
+      D = (uint32_t)(da >> 32);
+      ahead = (uint32_t)da;
+      off += n;
+      if ((i & 3u) == 3u) // rebuild the look-ahead from the staged words
+      {
+        bad |= (off - off_group > 32u || off > 95u) ? 1u : 0u;
+        off_group = off;
+        const uint32_t o = off & 31u;
+        const uint32_t lo = off < 32u ? w0 : (off < 64u ? w1 : w2), hi = off < 32u ? w1 : (off < 64u ? w2 : w3);
+        ahead = o ? (lo << o) | (hi >> (32u - o)) : lo;
+      }
+    }
+    bits_out = out;
+    bp = (uint64_t)k0 * 32u + off;
+    if (ADAPTIVE)
+      tot += 32u;
+    return (eof | bad) == 0;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Signed exp-Golomb parser + prefix sum (seg.c:45-94, diff.c:25-37) over the lane's decoded-bit ring.
+// ---------------------------------------------------------------------------------------------------------------------
+template <uint32_t BRING>
+struct SegParser
+{
+  const uint32_t *ring_col; // decoded bits, 32 per word, MSB first: ring[(k % BRING) * 64 + lane]
+  uint64_t pos;             // parse position (bits)
+  uint64_t avail;           // decoded bits available so far (exact once the lane saw EOF)
+  uint32_t last;            // diff.c:27
+
+  DG_DEV void init(const uint32_t *col)
+  {
+    ring_col = col;
+    pos = 0;
+    avail = 0;
+    last = 0;
+  }
+
+  DG_DEV uint32_t word(uint64_t k) const
+  {
+    return ring_col[((uint32_t)k % BRING) * 64u];
+  }
+
+  DG_DEV uint32_t bit(uint64_t p) const
+  {
+    return (word(p >> 5) >> (31u - ((uint32_t)p & 31u))) & 1u;
+  }
+
+  // Tries to parse one codeword.  Returns 1 and the sample if a complete codeword was available, 0 if more bits are
+  // needed (and `final` is false), 2 at a clean end of stream, or a negative error code.
+  DG_DEV int32_t next(bool final, uint32_t &sample)
+  {
+    if (pos >= avail)
+      return final ? 2 : 0;
+    // common case: the codeword lies in the next 32 bits (prefix <= 15) and is completely available
+    const uint32_t o = (uint32_t)pos & 31u;
+    const uint64_t k = pos >> 5;
+    uint32_t v = word(k) << o;
+    const uint64_t have = avail - pos;
+    if (o && have > 32u - o)
+      v |= word(k + 1) >> (32u - o);
+    if (have < 32)
+      v &= ~(0xFFFFFFFFu >> (uint32_t)have);
+    if (v != 0)
+    {
+      const uint32_t p = clz32(v);
+      const uint32_t n = 2u * p + 1u;
+      if (p <= 15 && n <= have)
+      {
+        const uint32_t w = v >> (32u - n);
+        const uint32_t mag = w >> 1;                 // (code_number + 1) / 2, seg.c:76
+        const uint32_t d = (w & 1u) ? 0u - mag : mag; // odd w = even code number = negative (seg.c:77-78)
+        last += d;                                   // diff.c:32-35
+        sample = last;
+        pos += n;
+        return 1;
+      }
+    }
+    // general case, bit by bit (long codewords, end of stream)
+    uint64_t q = pos;
+    uint32_t p = 0;
+    while (q < avail && bit(q) == 0) // seg.c:50-57
+    {
+      p++;
+      q++;
+      if (p >= 33)
+        return ERR_INVALID_FORMAT; // prefix cap: valuesize + 1 (seg.c:55-56,74)
+    }
+    if (q >= avail) // ran out inside the prefix
+      return final ? 2 : 0; // seg.c:58-62: EOF inside a non-empty zero prefix ends the stream (padding)
+    if (avail - q < (uint64_t)p + 1u)
+      return final ? ERR_LIBRARY_CALL : 0; // EOF inside the residual: a short read in the reference
+    q++; // the delimiting one
+    uint64_t r = 0;
+    for (uint32_t i = 0; i < p; i++)
+      r = (r << 1) | bit(q++);
+    const uint64_t code = (r | ((uint64_t)1 << p)) - 1u; // seg.c:65-66
+    const uint64_t mag = (code + 1u) >> 1;
+    const uint32_t d = (code & 1u) ? (uint32_t)mag : 0u - (uint32_t)mag; // odd code numbers are positive
+    last += d;
+    sample = last;
+    pos = q;
+    return 1;
+  }
+};
+
+} // namespace dg

@@ -178,3 +178,103 @@ def test_larger_batch_sampled_against_oracle(ctx):
     got_out = out.cpu().numpy()[sel]
     got_bits = bits.cpu().numpy().astype(np.uint64)[sel]
     assert_streams_equal(got_out, got_bits, np.zeros(len(sel), dtype=np.int32), *want, tag="large")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decode (bac -> seg -> prefix sum on the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def pad4(streams):
+    Cn, cap = streams.shape
+    if cap % 4 == 0:
+        return np.ascontiguousarray(streams)
+    out = np.zeros((Cn, (cap + 3) & ~3), dtype=np.uint8)
+    out[:, :cap] = streams
+    return out
+
+
+def test_decode_golden_channel_batches(ctx):
+    """The reference's own streams (tests/golden, generated by the compiled reference) decode to the original samples,
+    from exact bit lengths and from byte-padded ("file") lengths."""
+    z = np.load(os.path.join(GOLDEN, "channels.npz"))
+    names = sorted(k[:-2] for k in z.files if k.endswith(".x"))
+    for name in names:
+        x = z[name + ".x"]
+        T = x.shape[0]
+        for ad, tag in ((1, "ad"), (0, "st")):
+            st, gb, ge = z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)], z["%s.%s.err" % (name, tag)]
+            ok = ge == 0
+            y, err = ctx.decode_host(pad4(st[ok]), gb[ok], T, adaptive=ad)
+            assert (err == 0).all() and (y == x[:, ok]).all(), (name, tag)
+            y, err = ctx.decode_host(pad4(st[ok]), ((gb[ok] + 7) // 8) * 8, T, adaptive=ad)
+            assert (err == 0).all() and (y == x[:, ok]).all(), (name, tag, "padded")
+
+
+def test_decode_reference_test_file(ctx):
+    with gzip.open(os.path.join(GOLDEN, "input.txt.gz"), "rb") as f:
+        v = np.array(f.read().split(), dtype=np.float64).astype(np.float32)
+    with open(os.path.join(GOLDEN, "dega_adaptive.bin"), "rb") as f:
+        data = f.read()
+    cap = (len(data) + 3) & ~3
+    st = np.zeros((66, cap), dtype=np.uint8)
+    st[:, : len(data)] = np.frombuffer(data, dtype=np.uint8)
+    bits = np.full(66, 8 * len(data), dtype=np.uint64)  # the file: zero padded to a byte
+    out, err = ctx.decode_f32_host(st, bits, v.size, factor=100.0, adaptive=1)
+    assert (err == 0).all()
+    for c in (0, 1, 63, 64, 65):
+        assert out[:, c].tobytes() == v.tobytes()  # decode bac # decode seg # decode diff # decode normalize
+
+
+def test_decode_error_codes(ctx):
+    x = (np.cumsum(np.random.default_rng(8).integers(-50, 51, (200, 70)), axis=0) + 30000).astype(np.int32)
+    out, bits, err = ctx.encode_host(x, adaptive=1)
+    assert (err == 0).all()
+    # asking for the wrong number of samples
+    y, derr = ctx.decode_host(out, bits, 199, adaptive=1)
+    assert (derr == -3).all()
+    y, derr = ctx.decode_host(out, bits, 201, adaptive=1)
+    assert (derr == -3).all()
+    # truncated streams: the decoder runs out of bits (more than 14 phantom bits) or of samples
+    y, derr = ctx.decode_host(out, bits // 2, 200, adaptive=1)
+    assert (derr != 0).all()
+    # empty stream: ERROR_INVALID_FORMAT like the reference's decode bac on an empty file
+    y, derr = ctx.decode_host(out, np.zeros(70, dtype=np.uint64), 200, adaptive=1)
+    assert (derr == -3).all()
+    # the oracle gives the same verdict on a damaged stream
+    bad = out.copy()
+    bad[:, 40] ^= 0x5A
+    y, derr = ctx.decode_host(bad, bits, 200, adaptive=1)
+    oy, oerr = orc.decode_batch_tc(bad, bits, 200, 1)
+    assert ((derr == 0) == (oerr == 0)).all()
+    same = derr == 0
+    assert (y[:, same] == oy[:, same]).all()
+
+
+def test_round_trip_random_batches(ctx):
+    rng = np.random.default_rng(77)
+    for (T, Cn, S) in ((500, 700, 50), (96, 2000, 300), (1200, 150, 20000), (3, 130, 5), (1, 64, 100000)):
+        x = np.zeros((T, Cn), dtype=np.int64)
+        x[0] = rng.integers(0, 60000, Cn)
+        steps = rng.integers(-S, S + 1, (T, Cn)) * rng.integers(0, 3, Cn)[None, :]
+        for t in range(1, T):
+            x[t] = np.clip(x[t - 1] + steps[t], 0, 2**31 - 1)
+        x = x.astype(np.int32)
+        for ad in (1, 0):
+            out, bits, err = ctx.encode_host(x, adaptive=ad)
+            assert (err == 0).all()
+            y, derr = ctx.decode_host(out, bits, T, adaptive=ad)
+            assert (derr == 0).all() and (y == x).all(), (T, Cn, S, ad)
+
+
+def test_round_trip_large_device_resident(ctx):
+    """16 Ki channels x 4000 samples, encode -> decode on the device, compared on the device; checksums of the
+    streams' bit lengths are compared with the oracle on a sample of channels."""
+    import torch
+    Cn, T = 16384, 4000
+    x = ctx.synth(Cn, T, seed=4321, S=50)
+    cap = 4 * ((T * 3 + 67) // 4)
+    out, bits, err = ctx.encode(x, adaptive=1, cap=cap)
+    y, derr = ctx.decode(out, bits, T, adaptive=1)
+    torch.cuda.synchronize()
+    assert int((err != 0).sum()) == 0 and int((derr != 0).sum()) == 0
+    assert bool((y == x).all())

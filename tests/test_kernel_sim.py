@@ -90,3 +90,24 @@ def test_fast_word_path_equals_bit_path_on_random_and_nasty_states(sim):
         bad = sim.sim_fast_vs_slow(2024, 60000, ad, C.byref(fast), C.byref(redo))
         assert bad == 0
         assert fast.value > 30000 and redo.value > 1000  # both the fast path and the redo path were exercised
+
+
+def test_decode_kernel_logic_on_golden_sets(sim):
+    sim.sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    z = np.load(os.path.join(GOLDEN, "channels.npz"))
+    for name in ("walk300_T96", "ragged_small", "wild", "zeros"):
+        x = z[name + ".x"]
+        T = x.shape[0]
+        for ad, tag in ((1, "ad"), (0, "st")):
+            st, gb, ge = z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)], z["%s.%s.err" % (name, tag)]
+            ok = ge == 0
+            s2 = np.ascontiguousarray(st[ok])
+            if s2.shape[1] % 4:
+                s3 = np.zeros((s2.shape[0], (s2.shape[1] + 3) & ~3), dtype=np.uint8)
+                s3[:, : s2.shape[1]] = s2
+                s2 = s3
+            bits = np.ascontiguousarray(gb[ok])
+            y = np.zeros((T, s2.shape[0]), dtype=np.int32)
+            err = np.zeros(s2.shape[0], dtype=np.int32)
+            sim.sim_decode(s2.ctypes.data, s2.shape[1], bits.ctypes.data, s2.shape[0], T, s2.shape[0], ad, y.ctypes.data, err.ctypes.data)
+            assert (err == 0).all() and (y == x[:, ok]).all(), (name, tag)
