@@ -39,6 +39,7 @@ _SIGNATURES = {
     "dega_hip_worst_case_bytes": (_Z, [_Z]),
     "dega_hip_encode_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
     "dega_hip_decode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
+    "dega_hip_decode_var_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dega_hip_normalize_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, _P, _P, _P]),
     "dega_hip_denormalize_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, _P, _P]),
     "dega_hip_compact_offsets_dev": (C.c_int, [_P, _P, _Z, _P, _P]),
@@ -46,8 +47,10 @@ _SIGNATURES = {
     "dega_hip_synth_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "dega_hip_encode_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P]),
     "dega_hip_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P]),
+    "dega_hip_decode_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
     "dega_hip_decode_f32_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P]),
+    "dega_hip_decode_f32_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_profile": (C.c_int, [_P, C.c_int]),
     "dega_hip_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_int]),
 }
@@ -224,6 +227,20 @@ class Context:
         ret = library().dega_hip_decode_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, int(adaptive), 32, x.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_decode_host")
         return x, err
+
+    def decode_var_host(self, streams, bits, max_T, adaptive=1):
+        """Decode streams of unknown length: returns (x [max_T, C], counts uint64 [C], err)."""
+        import numpy as np
+        streams = np.ascontiguousarray(streams, dtype=np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn, cap = streams.shape
+        x = np.zeros((max_T, Cn), dtype=np.int32)
+        counts = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_decode_var_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, max_T, Cn, int(adaptive), 32,
+                                                 x.ctypes.data, counts.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_decode_var_host")
+        return x, counts, err
 
     def encode_f32_host(self, v_tc, factor=100.0, adaptive=1, cap=None):
         import numpy as np

@@ -245,8 +245,8 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   return DEGA_OK;
 }
 
-extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                                   int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
+static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                         int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
 {
   int ret;
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
@@ -264,6 +264,7 @@ extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t 
   a.x = x_tc;
   a.err = err;
   a.div_magic = ctx->div_magic;
+  a.out_count = out_count;
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {
@@ -275,6 +276,20 @@ extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t 
   }
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                   int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
+{
+  return launch_decode(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err, stream);
+}
+
+extern "C" int dega_hip_decode_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                       int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
+{
+  if (out_count == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  return launch_decode(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err, stream);
 }
 
 static dim3 rowsplit_grid(size_t C, size_t T)
@@ -431,8 +446,25 @@ extern "C" int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size
   return DEGA_OK;
 }
 
+static int decode_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                            int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
+
 extern "C" int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                     int adaptive, int valuesize, int32_t *x_tc, int32_t *err)
+{
+  return decode_host_impl(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err);
+}
+
+extern "C" int dega_hip_decode_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                        int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
+{
+  if (out_count == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  return decode_host_impl(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err);
+}
+
+static int decode_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                            int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
 {
   int ret;
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
@@ -448,11 +480,17 @@ extern "C" int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t
   HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+  DevBuf dcount;
+  if (out_count != nullptr)
+    HIP_TRY(ctx, dcount.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  if ((ret = launch_decode(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
+                           out_count != nullptr ? (uint64_t *)dcount.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
     return ret;
   HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, T * ld * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  if (out_count != nullptr)
+    HIP_TRY(ctx, hipMemcpy(out_count, dcount.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }
 
@@ -490,8 +528,25 @@ extern "C" int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, si
   return DEGA_OK;
 }
 
+static int decode_f32_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err);
+
 extern "C" int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                         float factor, int adaptive, int valuesize, float *v_tc, int32_t *err)
+{
+  return decode_f32_host_impl(ctx, in, cap, in_bits, C, T, ld, factor, adaptive, valuesize, v_tc, nullptr, err);
+}
+
+extern "C" int dega_hip_decode_f32_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                            float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err)
+{
+  if (out_count == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  return decode_f32_host_impl(ctx, in, cap, in_bits, C, max_T, ld, factor, adaptive, valuesize, v_tc, out_count, err);
+}
+
+static int decode_f32_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err)
 {
   int ret;
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
@@ -508,8 +563,14 @@ extern "C" int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, si
   HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+  DevBuf dcount;
+  if (out_count != nullptr)
+    HIP_TRY(ctx, dcount.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  if ((ret = launch_decode(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
+                           out_count != nullptr ? (uint64_t *)dcount.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
     return ret;
+  if (out_count != nullptr)
+    HIP_TRY(ctx, hipMemcpy(out_count, dcount.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   if ((ret = dega_hip_denormalize_dev(ctx, (const int32_t *)dx.p, C, T, ld, factor, valuesize, (float *)dv.p, nullptr)) != DEGA_OK)
     return ret;
   HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);

@@ -340,6 +340,7 @@ struct DecodeArgs
   int32_t *x; // [T][ld]
   int32_t *err;
   const uint32_t *div_magic;
+  uint64_t *out_count; // NULL: every channel must hold exactly T samples.  Else: up to T samples, count reported here
 };
 
 template <bool ADAPTIVE>
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
               if (t_lane >= a.T)
               {
                 if (lane_err == OK)
-                  lane_err = ERR_INVALID_FORMAT; // more samples than the caller asked for
+                  lane_err = a.out_count != nullptr ? ERR_MEMORY : ERR_INVALID_FORMAT; // more samples than room / than asked for
                 lane_final = true;
                 stalled = true;
               }
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
             {
               if (r < 0 && lane_err == OK)
                 lane_err = r;
-              if (r == 2 && t_lane != a.T && lane_err == OK)
+              if (r == 2 && t_lane != a.T && a.out_count == nullptr && lane_err == OK)
                 lane_err = ERR_INVALID_FORMAT; // fewer samples than the caller asked for
               lane_final = true;
               stalled = true;
@@ -538,13 +539,14 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
       }
     }
     // ---- phase W: rows every lane has ----------------------------------------------------------------------------------
-    while (rows_stored < a.T && wave_all(lane_final || t_lane > rows_stored))
+    // (with a reported count, rows past the longest channel of the wave are not written at all)
+    while (rows_stored < a.T && wave_all(lane_final || t_lane > rows_stored) && (a.out_count == nullptr || wave_any(t_lane > rows_stored)))
     {
       if (live)
         a.x[rows_stored * a.ld + c] = t_lane > rows_stored ? (int32_t)sring[(rows_stored % DEC_SRING) * 64u] : 0;
       rows_stored++;
     }
-    if (rows_stored >= a.T && wave_all(lane_final))
+    if (wave_all(lane_final) && (rows_stored >= a.T || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
     // ---- phase R ------------------------------------------------------------------------------------------------------
     iter++;
@@ -556,7 +558,11 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
     }
   }
   if (live)
+  {
     a.err[c] = lane_err;
+    if (a.out_count != nullptr)
+      a.out_count[c] = t_lane;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

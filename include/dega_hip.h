@@ -68,6 +68,12 @@ int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t
 int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                         int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream);
 
+/* Like dega_hip_decode_dev, for streams whose sample count is not known (a DCLib stream has no header: the count is
+   implied by the EOF symbol, bac.c:256): decodes up to max_T samples per channel and reports each channel's count in
+   out_count[c]; a channel holding more than max_T samples gets DEGA_ERROR_MEMORY (call again with more room). */
+int dega_hip_decode_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                            int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream);
+
 /* ---- float entry / exit (normalize.c), device pointers ----------------------------------------------------------- */
 /* v: float32 [T][ld] -> x: int32 [T][ld]; err[c] = DEGA_ERROR_INVALID_VALUE if any sample of channel c fails the range check. */
 int dega_hip_normalize_dev(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int valuesize,
@@ -93,11 +99,16 @@ int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_
                          uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
 int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                          int adaptive, int valuesize, int32_t *x_tc, int32_t *err);
+int dega_hip_decode_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                             int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
 /* float32 channels in, DEGA streams out: normalize + encode fused on the device (and the inverse). */
 int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
                              uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
 int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                              float factor, int adaptive, int valuesize, float *v_tc, int32_t *err);
+
+int dega_hip_decode_f32_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                 float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err);
 
 /* ---- measurement hook ---------------------------------------------------------------------------------------------- */
 /* Average duration in milliseconds of the encode (which=0) / decode (which=1) kernel launches enqueued since the last

@@ -39,7 +39,7 @@ extern "C" __attribute__((visibility("default"))) int sim_encode(const int32_t *
 extern "C" __attribute__((visibility("default"))) int sim_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
-  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data()};
+  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr};
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   if (adaptive)
     sim::launch(dega_decode_kernel<true>, grid, dim3(BLOCK), a);
