@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--step-size", type=int, default=50, help="S of the synthetic random walk")
     ap.add_argument("--cap-bytes-per-sample", type=float, default=4.0, help="slab bytes per sample per channel")
     ap.add_argument("--cpu-channels", type=int, default=256, help="channels of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-round-trip", action="store_true", help="skip the decode + compare after the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,6 +113,25 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
 
+    # bit-exact round trip at full size (the size-independent property of the metric): decode every stream on the
+    # device and compare with the input on the device
+    round_trip = None
+    if not args.no_round_trip:
+        y = torch.zeros((T, C_), dtype=torch.int32, device=dev)
+        derr = torch.zeros(C_, dtype=torch.int32, device=dev)
+        ctx.profile(True)
+        ctx.decode(out, bits, T, adaptive=1, x_tc=y, err=derr)
+        torch.cuda.synchronize()
+        ctx.profile(False)
+        _, dec_ms = ctx.profile_read(1)
+        ok = bool((y == x).all().item()) and int((derr != 0).sum().item()) == 0
+        flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        round_trip = {"bit_exact": bool(flags.item()), "decode_kernel_ms": round(dec_ms, 3),
+                      "decode_msamples_per_s_per_gpu": round(C_ * T / (dec_ms * 1e-3) / 1e6, 1) if dec_ms > 0 else None}
+        del y
+
     n_err = int((err != 0).sum().item())
     out_bytes = int(((bits + 7) // 8).sum().item())
     algo_bytes = 4.0 * C_ * T + out_bytes  # 4 B read per sample + compressed bytes written, per launch
@@ -151,6 +171,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(algo_bytes),
             },
         }
+        if round_trip is not None:
+            res["round_trip"] = round_trip
         if world == 1 and args.cpu_channels > 0:
             n = min(args.cpu_channels, C_)
             res["cpu_baseline"] = cpu_baseline(x[:, :n].cpu().numpy(), out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
