@@ -52,11 +52,22 @@ DG_DEV void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t /*lan
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_row, 4, 0, 0);
 }
+// Four dwords per lane (16-byte aligned source): lane l's 16 bytes land at lds_base + 16*l.
+DG_DEV void dma_x4_to_lds(const int32_t *src, uint32_t *lds_base, uint32_t /*lane*/)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
 DG_DEV void wait_vector_memory()
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #else
+inline void dma_x4_to_lds(const int32_t *src, uint32_t *lds_base, uint32_t lane)
+{
+  for (uint32_t k = 0; k < 4; k++)
+    lds_base[lane * 4 + k] = (uint32_t)src[k];
+}
 inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
 {
   lds_row[lane] = (uint32_t)*src;
@@ -139,8 +150,23 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   const int32_t *const last_row = a.x + t_last * a.ld;
   const uint32_t col_idx = live ? (uint32_t)c : 0u; // C <= 2^32 columns
 
+  // When the wave's 64 channels all exist and rows are 16-byte aligned, one LDS-DMA instruction fetches FOUR rows:
+  // lanes 16r .. 16r+15 read row r's 256 bytes as 16-byte pieces, which land as row r of the [row][64] LDS image.
+  const size_t c_wave0 = (size_t)blockIdx.x * BLOCK + wave * 64u;
+  const bool rows_x4 = (ENC_ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
   auto issue_rows = [&](size_t t0) // rows [t0, t0 + ENC_ROWS), clamped to the last row
   {
+    if (rows_x4)
+    {
+      const uint32_t r = lane >> 4, q = lane & 15u;
+#pragma unroll
+      for (uint32_t j = 0; j < ENC_ROWS / 4; j++)
+      {
+        const size_t row = t0 + 4 * j + r < a.T ? t0 + 4 * j + r : t_last;
+        dma_x4_to_lds(a.x + row * a.ld + c_wave0 + q * 4u, rows_wave + j * 256u, lane);
+      }
+      return;
+    }
     const int32_t *rowp = a.x + t0 * a.ld; // wave uniform; the lane adds its 32-bit column index
 #pragma unroll
     for (uint32_t i = 0; i < ENC_ROWS; i++)

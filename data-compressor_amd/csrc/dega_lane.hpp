@@ -79,10 +79,39 @@ DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // m
 #endif
 }
 
+// Number of leading one bits of x, for x with bit 31 set and not all ones (v_ffbh_i32 counts the bits equal to the sign).
+DG_DEV uint32_t leading_ones(uint32_t x)
+{
+#if defined(DEGA_SIM)
+  return (uint32_t)__builtin_clz(~x);
+#else
+  uint32_t r;
+  asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#endif
+}
+
+// W += add (64 bit), carries += carry out -- three chained adds
+DG_DEV void add64_count_carry(uint64_t &W, uint64_t add, uint32_t &carries)
+{
+#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 128))
+  const uint64_t nw = W + add;
+  carries += nw < add ? 1u : 0u;
+  W = nw;
+#else
+  uint32_t lo = (uint32_t)W, hi = (uint32_t)(W >> 32);
+  asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+      : "+v"(lo), "+v"(hi), "+v"(carries)
+      : "v"((uint32_t)add), "v"((uint32_t)(add >> 32))
+      : "vcc");
+  W = ((uint64_t)hi << 32) | lo;
+#endif
+}
+
 // (~x) >> 16 in one instruction (SDWA: NOT of the high word, written zero-extended)
 DG_DEV uint32_t not_hi16(uint32_t x)
 {
-#if defined(DEGA_SIM)
+#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 64))
   return (~x) >> 16;
 #else
   uint32_t r;
@@ -378,21 +407,21 @@ struct BacEncoder
       const uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for an LPS
       const uint32_t Rm1 = not_hi16(A + B);
       const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 256)
+      const uint32_t x2 = mulhi32(Rm1 + 1u, M) >> sh;
+#else
       const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
+#endif
       const uint32_t inc = select32(lm, x2, x1);
       B = select32(lm, 0u - (A + (x1 << 16)), B);
       A += inc << 16;
       if (ADAPTIVE)
         c1 -= lm; // f2++ for an LPS; tot is implicit (mg[i])
       // output accumulator
-      const uint64_t add = (uint64_t)inc << wsh;
-      const uint64_t nw = W + add;
-      pc += nw < add ? 1u : 0u;
-      W = nw;
+      add64_count_carry(W, (uint64_t)inc << wsh, pc);
       // renormalise
       const uint32_t k = clz32(~(A ^ B));
-      const uint32_t v = ((A & B) << k) | 0x80000000u;
-      const uint32_t n = k + clz32(~v) - 1u;
+      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
       A <<= n;
       B <<= n;
       wsh -= n;
@@ -459,13 +488,9 @@ struct BacEncoder
       const uint32_t inc = select32(lm, x2, x1);
       B = select32(lm, 0u - (A + (x1 << 16)), B);
       A += inc << 16;
-      const uint64_t add = (uint64_t)inc << wsh;
-      const uint64_t nw = W + add;
-      pc += nw < add ? 1u : 0u;
-      W = nw;
+      add64_count_carry(W, (uint64_t)inc << wsh, pc);
       const uint32_t k = clz32(~(A ^ B));
-      const uint32_t v = ((A & B) << k) | 0x80000000u;
-      const uint32_t n = k + clz32(~v) - 1u;
+      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
       A <<= n;
       B <<= n;
       wsh -= n;
@@ -575,10 +600,18 @@ struct BitQueue
   }
 
   // a codeword of value w < 2^16: 2p+1 <= 31 bits, one piece (its leading zeros are the prefix, seg.c:18-19)
+  // Branch free (a divergent `if` would cost its exec-mask bookkeeping on every row): the word slot is written
+  // unconditionally -- with garbage while the accumulator holds fewer than 32 bits, overwritten by the real word later.
   template <uint32_t RING>
   DG_DEV void put_short(uint32_t w, uint32_t *ring_col)
   {
-    put<RING>(w, 63u - 2u * clz32(w), ring_col);
+    const uint32_t n = 63u - 2u * clz32(w);
+    acc = (acc << n) | w;
+    cnt += n;
+    const uint32_t full = cnt >= 32u ? 1u : 0u;
+    ring_col[(wr % RING) * 64u] = (uint32_t)(acc >> ((cnt - 32u) & 63u));
+    wr += full;
+    cnt -= full << 5;
   }
 
   template <uint32_t RING>
@@ -797,8 +830,7 @@ struct BacDecoder
       if (ADAPTIVE)
         c1 -= lm;
       const uint32_t k = clz32(~(A ^ B));
-      const uint32_t v = ((A & B) << k) | 0x80000000u;
-      const uint32_t n = k + clz32(~v) - 1u;
+      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
       A <<= n;
       B <<= n;
       const uint64_t da = (((uint64_t)D << 32) | ahead) << n; // D takes the next n bits
