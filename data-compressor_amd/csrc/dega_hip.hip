@@ -208,8 +208,10 @@ static int check_shape(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t 
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "valuesize must be 32 for the [T][C] int32 layout", hipSuccess);
   if (ld < C)
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "ld < C", hipSuccess);
-  if (cap % 4 != 0 || cap / 4 > 0xFFFFFFFFull)
-    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "cap must be a multiple of 4 (and < 16 GiB)", hipSuccess);
+  if (cap % 4 != 0 || cap > ((size_t)1 << 29))
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "cap must be a multiple of 4 and at most 512 MiB", hipSuccess);
+  if (T > ((size_t)1 << 25))
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "at most 2^25 samples per channel and call", hipSuccess);
   return DEGA_OK;
 }
 

@@ -33,6 +33,26 @@ DG_DEV bool wave_all(bool p)
 {
   return __all((int)p) != 0;
 }
+DG_DEV uint32_t wave_min_u32(uint32_t v) // butterfly over the 64 lanes
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+  {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+DG_DEV uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+  {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
 #endif
 
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
@@ -193,8 +213,13 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     {
       // wave uniform choice: the fast word (no model event possible in it), the general word (halving / swap / shift
       // change handled branch free), or bit by bit (first word of a channel, leftovers in the LDS column)
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 1024)
+      const bool fast = iter > 8; // diagnostic build: no precondition ballots
+      const bool general = false;
+#else
       const bool fast = wave_all(!has || enc.fast_ok());
       const bool general = ADAPTIVE && !fast && wave_all(!has || enc.general_ok());
+#endif
       if (has)
       {
         const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
@@ -207,6 +232,9 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
             done = enc.encode_word_fast(word, tab);
           else if constexpr (ADAPTIVE)
             done = enc.encode_word_general(word, tab);
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 512)
+          done = true; // diagnostic build: no checkpoint / redo
+#endif
           if (!done)
             enc = checkpoint; // a carry ran past the held-back word, or > 48 bits piled up: redo exactly
         }
@@ -353,7 +381,6 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 //                                     (LDS-DMA into a staging row; copied to the lane's own ring slots after the wait).
 // =====================================================================================================================
 constexpr uint32_t DEC_IRING = 16; // staged stream words per lane
-constexpr uint32_t DEC_BRING = 8;  // decoded seg-bit words per lane
 constexpr uint32_t DEC_SRING = 16; // decoded samples per lane
 constexpr uint32_t DEC_REFILL_EVERY = 4;
 
@@ -373,7 +400,7 @@ template <bool ADAPTIVE>
 __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + DEC_BRING + DEC_SRING) * 64;
+  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + DEC_SRING + 1) * 64; // + a spare sample slot
   __shared__ uint32_t lds[TAB_WORDS + WAVES * PER_WAVE];
   uint32_t *const tab = lds;
   load_div_table<ADAPTIVE>(tab, a.div_magic);
@@ -385,30 +412,28 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
   uint32_t *const wave_lds = lds + TAB_WORDS + wave * PER_WAVE;
   uint32_t *const iring = wave_lds + lane;                               // staged stream words
   uint32_t *const stage_wave = wave_lds + DEC_IRING * 64;                // DMA landing rows (wave uniform)
-  uint32_t *const bring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded seg bits
-  uint32_t *const sring = wave_lds + (DEC_IRING + 4 + DEC_BRING) * 64 + lane; // decoded samples
+  uint32_t *const sring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded samples
 
   const uint32_t cap_words = (uint32_t)(a.cap / 4);
   const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
   const uint64_t nbits = live ? a.in_bits[c] : 0;
   const uint32_t total_words = (uint32_t)((nbits + 31) / 32) < cap_words ? (uint32_t)((nbits + 31) / 32) : cap_words;
-  const uint64_t max_seg_bits = (uint64_t)a.T * 65u; // no valid stream of T samples decodes to more bits
+  const uint32_t max_seg_bits = (uint32_t)a.T * 65u; // no valid stream of T samples decodes to more bits (T <= 2^25)
 
   StreamWindow<DEC_IRING> in;
   in.ring_col = iring;
   in.nbits = nbits;
   BacDecoder<ADAPTIVE> dec;
   dec.init();
-  SegParser<DEC_BRING> sp;
-  sp.init(bring);
+  SegParser sp;
+  sp.init();
+  uint32_t seg_bits = 0; // seg bits decoded so far
 
   uint32_t in_loaded = 0;    // stream words staged so far (a multiple of 4 until the end)
   uint32_t requested = 0;    // words requested by the DMA in flight (0 or up to 4)
   bool started = false;      // StartDecoding done
   bool bac_done = !live;     // EOF symbol seen (or error)
   bool lane_final = !live;   // nothing more will come out of this lane
-  uint32_t bw = 0;           // decoded-bit words written
-  uint32_t part = 0, part_n = 0; // partial last word being assembled by the bit-by-bit path
   size_t t_lane = 0;         // samples produced
   size_t rows_stored = 0;    // wave uniform
   int32_t lane_err = OK;
@@ -429,8 +454,10 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
   };
   request_refill();
 
+  DG_STAMP_DECL;
   for (;;)
   {
+    DG_STAMP(7);
     // ---- phase C ---------------------------------------------------------------------------------------------------
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
     const uint32_t need_words = k0 + 4u < total_words ? k0 + 4u : total_words; // words the next 32 symbols may touch
@@ -440,8 +467,8 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
       dec.start(in);
       started = true;
     }
-    const bool can = live && started && !bac_done && input_ok && (uint64_t)bw - (sp.pos >> 5) < DEC_BRING && part_n == 0;
-    const bool can_slow = live && started && !bac_done && input_ok && (uint64_t)bw - (sp.pos >> 5) < DEC_BRING;
+    const bool can = live && started && !bac_done && input_ok && sp.has_room();
+    const bool can_slow = can;
     const bool any_can = wave_any(can_slow);
     if (any_can)
     {
@@ -449,16 +476,17 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
       if (can_slow)
       {
         bool done = false;
-        if (fast)
         {
           const BacDecoder<ADAPTIVE> checkpoint = dec;
-          uint32_t bits;
-          done = dec.decode_word_fast(in, tab, bits);
+          uint32_t bits = 0;
+          if (fast)
+            done = dec.template decode_word<false>(in, tab, bits);
+          else if constexpr (ADAPTIVE)
+            done = dec.template decode_word<true>(in, tab, bits); // halving / swap / shift change somewhere in the wave
           if (done)
           {
-            bring[(bw % DEC_BRING) * 64u] = bits;
-            bw++;
-            sp.avail += 32;
+            sp.push(bits, 32);
+            seg_bits += 32;
           }
           else
             dec = checkpoint;
@@ -478,25 +506,11 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
             }
             else
             {
-              part = (part << 1) | r;
-              part_n++;
-              sp.avail++;
-              if (part_n == 32)
-              {
-                bring[(bw % DEC_BRING) * 64u] = part;
-                bw++;
-                part = 0;
-                part_n = 0;
-              }
+              sp.push(r, 1);
+              seg_bits++;
             }
           }
-          if (bac_done && part_n > 0)
-          {
-            bring[(bw % DEC_BRING) * 64u] = part << (32u - part_n);
-            bw++;
-            part_n = 0;
-          }
-          if (!bac_done && sp.avail > max_seg_bits)
+          if (!bac_done && seg_bits > max_seg_bits)
           {
             bac_done = true; // runaway stream: cannot be T samples
             if (lane_err == OK)
@@ -505,6 +519,15 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
         }
       }
     }
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+    if (any_can)
+    {
+      if (wave_all(!can_slow || (can && dec.fast_ok())))
+        DG_STAMP(3);
+      else
+        DG_STAMP(4);
+    }
+#endif
     // ---- the DMA issued at the end of the previous step has landed: move the words to the lane's own ring slots -----
     wait_vector_memory();
     if (requested > 0)
@@ -516,9 +539,29 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
       in_loaded += requested;
       requested = 0;
     }
+    DG_STAMP(5);
     // ---- phase S: parse what is there --------------------------------------------------------------------------------
     {
-      bool stalled = lane_final;
+      // (1) the steady state, branch free: up to 4 short codewords per pass; a lane that cannot take one writes to a
+      //     spare slot of its sample column instead
+      bool more = true;
+      while (wave_any(more))
+      {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+        {
+          uint32_t sample;
+          const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
+          const bool took = sp.take_short(allowed, sample);
+          sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
+          t_lane += took ? 1u : 0u;
+          more = took;
+        }
+        DG_STAMP(2);
+      }
+      // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;
+      //     entered only by lanes that cannot simply wait for more bits
+      bool stalled = lane_final || t_lane - rows_stored >= DEC_SRING || !(bac_done || sp.cnt >= 32u || (sp.need | sp.zeros) != 0u);
       while (wave_any(!stalled))
       {
         if (!stalled)
@@ -564,16 +607,36 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
         bac_done = true;
       }
     }
+    DG_STAMP(1);
     // ---- phase W: rows every lane has ----------------------------------------------------------------------------------
     // (with a reported count, rows past the longest channel of the wave are not written at all)
-    while (rows_stored < a.T && wave_all(lane_final || t_lane > rows_stored) && (a.out_count == nullptr || wave_any(t_lane > rows_stored)))
+    // Up to 4 rows per pass: the 4 candidate samples are read from the ring at once (one LDS wait), then each row that
+    // every lane has is stored.  (With a reported count, rows past the longest channel of the wave are not written.)
+    for (;;)
     {
-      if (live)
-        a.x[rows_stored * a.ld + c] = t_lane > rows_stored ? (int32_t)sring[(rows_stored % DEC_SRING) * 64u] : 0;
-      rows_stored++;
+      uint32_t cand[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        cand[k] = sring[((rows_stored + k) % DEC_SRING) * 64u];
+      uint32_t wrote = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+      {
+        const size_t row = rows_stored + k;
+        if (wrote == k && row < a.T && wave_all(lane_final || t_lane > row) && (a.out_count == nullptr || wave_any(t_lane > row)))
+        {
+          if (live)
+            a.x[row * a.ld + c] = t_lane > row ? (int32_t)cand[k] : 0;
+          wrote = k + 1;
+        }
+      }
+      rows_stored += wrote;
+      if (wrote < 4)
+        break;
     }
     if (wave_all(lane_final) && (rows_stored >= a.T || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
+    DG_STAMP(6);
     // ---- phase R ------------------------------------------------------------------------------------------------------
     iter++;
     {
@@ -582,12 +645,20 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
       if ((iter % DEC_REFILL_EVERY) == 0 || wave_any(low))
         request_refill();
     }
+    DG_STAMP(0);
   }
   if (live)
   {
     a.err[c] = lane_err;
     if (a.out_count != nullptr)
       a.out_count[c] = t_lane;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+    uint64_t *dbg = const_cast<uint64_t *>(a.in_bits); // diagnostic build only: dump the stamps over in_bits
+    if (lane < 8)
+      dbg[c] = stamp_sum[lane];
+    else if (lane < 16)
+      dbg[c] = stamp_cnt[lane - 8];
+#endif
   }
 }
 

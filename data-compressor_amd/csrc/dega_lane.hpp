@@ -794,29 +794,54 @@ struct BacDecoder
   // 32 symbols, branch free.  Needs the words bp/32 .. bp/32 + 3 staged.  Returns false -- the caller restores its
   // checkpoint and goes bit by bit -- if an EOF symbol turned up, or if one group of 4 symbols consumed more than 32
   // stream bits (the 32-bit look-ahead is rebuilt every 4 symbols), or if the word needed more than the 4 staged words.
-  template <uint32_t IRING>
-  DG_DEV bool decode_word_fast(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t &bits_out)
+  // GENERAL = false: no model event (halving, MPS/LPS swap, division-shift change) can occur in the word (fast_ok()).
+  // GENERAL = true : the whole model update of bac.c:54-81 by selects, as in BacEncoder::encode_word_general.
+  template <bool GENERAL, uint32_t IRING>
+  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t &bits_out)
   {
     const uint32_t *const mg = magic + tot;
-    const uint32_t sh = div_shift(tot);
+    const uint32_t sh_fast = div_shift(tot);
     uint32_t Mg[32];
+    if (!GENERAL)
+    {
 #pragma unroll
-    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-      Mg[i] = mg[i];
+      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+        Mg[i] = mg[i];
+    }
+    uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
     const uint32_t w0 = in.word(k0), w1 = in.word(k0 + 1u), w2 = in.word(k0 + 2u), w3 = in.word(k0 + 3u);
+    if (!GENERAL)
+    {
 #pragma unroll
-    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-      DG_MATERIALISE(Mg[i]);
-    uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2
+      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+        DG_MATERIALISE(Mg[i]);
+    }
+    uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2:w3
     uint32_t off_group = off;
     uint32_t ahead = off ? (w0 << off) | (w1 >> (32u - off)) : w0; // next 32 stream bits, left aligned
-    const uint32_t mm = 0u - mps;
+    uint32_t mm = 0u - mps;
     uint32_t out = 0, eof = 0, bad = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 32; i++)
     {
-      const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
+      uint32_t M, sh, c1u = c1, totu = tot, Mnext = 0;
+      if (GENERAL)
+      {
+        const bool halve = tot == MAX_FREQUENCY;
+        const uint32_t c1h = (c1 >> 1) + 1u;
+        const uint32_t toth = ((tot - c1 + 1u) >> 1) + c1h;
+        c1u = halve ? c1h : c1;
+        totu = halve ? toth : tot;
+        Mnext = magic[totu + 1u];
+        M = Mcur;
+        sh = div_shift(tot);
+      }
+      else
+      {
+        M = ADAPTIVE ? Mg[i] : Mg[0];
+        sh = sh_fast;
+      }
       const uint32_t Rm1 = not_hi16(A + B);
       const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
       const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
@@ -827,7 +852,15 @@ struct BacDecoder
       A += inc << 16;
       D -= inc;
       out = (out << 1) | ((lm ^ mm) & 1u);
-      if (ADAPTIVE)
+      if (GENERAL)
+      {
+        const uint32_t tie = (c1u - 1u == totu - c1u) ? 0xFFFFFFFFu : 0u;
+        mm ^= lm & tie;
+        c1 = c1u - (lm & ~tie);
+        tot = totu + 1u;
+        Mcur = Mnext;
+      }
+      else if (ADAPTIVE)
         c1 -= lm;
       const uint32_t k = clz32(~(A ^ B));
       const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
@@ -848,7 +881,9 @@ struct BacDecoder
     }
     bits_out = out;
     bp = (uint64_t)k0 * 32u + off;
-    if (ADAPTIVE)
+    if (GENERAL)
+      mps = mm & 1u;
+    else if (ADAPTIVE)
       tot += 32u;
     return (eof | bad) == 0;
   }
@@ -857,86 +892,117 @@ struct BacDecoder
 // ---------------------------------------------------------------------------------------------------------------------
 // Signed exp-Golomb parser + prefix sum (seg.c:45-94, diff.c:25-37) over the lane's decoded-bit ring.
 // ---------------------------------------------------------------------------------------------------------------------
-template <uint32_t BRING>
+// The decoded seg bits never go to memory: the arithmetic decoder appends them to a 64-bit register window (at most 32
+// at a time, when the window holds <= 32), and the parser takes codewords off its top.  Codewords longer than the
+// window (up to 65 bits) are parsed in two parts: first the zero prefix (possibly over several refills), then the
+// delimiting one with its residual (<= 33 bits).
 struct SegParser
 {
-  const uint32_t *ring_col; // decoded bits, 32 per word, MSB first: ring[(k % BRING) * 64 + lane]
-  uint64_t pos;             // parse position (bits)
-  uint64_t avail;           // decoded bits available so far (exact once the lane saw EOF)
-  uint32_t last;            // diff.c:27
+  uint64_t win;    // valid bits left aligned
+  uint32_t cnt;    // number of valid bits in win
+  uint32_t zeros;  // zero-prefix bits of the current codeword consumed so far
+  uint32_t need;   // 0: scanning a prefix; else: prefix done, need = its length + 1 bits are wanted next
+  uint32_t last;   // diff.c:27
 
-  DG_DEV void init(const uint32_t *col)
+  DG_DEV void init()
   {
-    ring_col = col;
-    pos = 0;
-    avail = 0;
+    win = 0;
+    cnt = 0;
+    zeros = 0;
+    need = 0;
     last = 0;
   }
 
-  DG_DEV uint32_t word(uint64_t k) const
+  DG_DEV bool has_room() const // for 32 more bits
   {
-    return ring_col[((uint32_t)k % BRING) * 64u];
+    return cnt <= 32u;
   }
 
-  DG_DEV uint32_t bit(uint64_t p) const
+  DG_DEV void push(uint32_t bits, uint32_t n) // n <= 32 bits, right aligned in `bits`; cnt + n <= 64
   {
-    return (word(p >> 5) >> (31u - ((uint32_t)p & 31u))) & 1u;
+    if (n > 0)
+    {
+      win |= (uint64_t)bits << (64u - n) >> cnt;
+      cnt += n;
+    }
+  }
+
+  DG_DEV void drop(uint32_t n) // n <= cnt, n <= 63... (n == 64 only when cnt == 64)
+  {
+    win = n >= 64u ? 0 : win << n;
+    cnt -= n;
+  }
+
+  DG_DEV void emit(uint64_t w, uint32_t &sample) // w = code_number + 1
+  {
+    const uint32_t mag = (uint32_t)(w >> 1);       // (code_number + 1) / 2, seg.c:76
+    const uint32_t d = (w & 1u) ? 0u - mag : mag;  // odd w = even code number = negative (seg.c:77-78)
+    last += d;                                     // diff.c:32-35
+    sample = last;
+  }
+
+  // Branch-free attempt at the common case: a whole codeword of <= 31 bits on top of the window, parser between
+  // codewords, `allowed` (room in the sample ring, count below T, lane not finished).  Returns true and the sample if it
+  // took one; otherwise changes nothing.
+  DG_DEV bool take_short(bool allowed, uint32_t &sample)
+  {
+    const uint32_t top = (uint32_t)(win >> 32);
+    const uint32_t p = clz32(top | 0x8000u); // 16 = no short codeword here
+    const uint32_t n = 2u * p + 1u;
+    const bool ok = allowed && (need | zeros) == 0u && p <= 15u && n <= cnt;
+    const uint32_t w = top >> ((32u - n) & 31u);
+    const uint32_t mag = w >> 1;
+    const uint32_t d = (w & 1u) ? 0u - mag : mag;
+    const uint32_t m = ok ? n : 0u;
+    last += ok ? d : 0u;
+    sample = last;
+    win <<= m;
+    cnt -= m;
+    return ok;
   }
 
   // Tries to parse one codeword.  Returns 1 and the sample if a complete codeword was available, 0 if more bits are
   // needed (and `final` is false), 2 at a clean end of stream, or a negative error code.
   DG_DEV int32_t next(bool final, uint32_t &sample)
   {
-    if (pos >= avail)
-      return final ? 2 : 0;
-    // common case: the codeword lies in the next 32 bits (prefix <= 15) and is completely available
-    const uint32_t o = (uint32_t)pos & 31u;
-    const uint64_t k = pos >> 5;
-    uint32_t v = word(k) << o;
-    const uint64_t have = avail - pos;
-    if (o && have > 32u - o)
-      v |= word(k + 1) >> (32u - o);
-    if (have < 32)
-      v &= ~(0xFFFFFFFFu >> (uint32_t)have);
-    if (v != 0)
+    if (need == 0 && zeros == 0)
     {
-      const uint32_t p = clz32(v);
+      // common case: a whole codeword of <= 31 bits on top of the window
+      const uint32_t top = (uint32_t)(win >> 32);
+      const uint32_t p = top ? clz32(top) : 32u;
       const uint32_t n = 2u * p + 1u;
-      if (p <= 15 && n <= have)
+      if (p <= 15u && n <= cnt)
       {
-        const uint32_t w = v >> (32u - n);
-        const uint32_t mag = w >> 1;                 // (code_number + 1) / 2, seg.c:76
-        const uint32_t d = (w & 1u) ? 0u - mag : mag; // odd w = even code number = negative (seg.c:77-78)
-        last += d;                                   // diff.c:32-35
-        sample = last;
-        pos += n;
+        emit(top >> (32u - n), sample);
+        drop(n);
         return 1;
       }
+      if (cnt == 0)
+        return final ? 2 : 0;
+      // Fewer than 32 bits on hand and more to come: whatever the codeword is, it is not complete yet (a complete one
+      // of <= 31 bits was taken above, longer ones need more than 32 bits).  Leave the window untouched, so that the
+      // branch-free take_short() can have the codeword once it is whole.
+      if (!final && cnt < 32u)
+        return 0;
     }
-    // general case, bit by bit (long codewords, end of stream)
-    uint64_t q = pos;
-    uint32_t p = 0;
-    while (q < avail && bit(q) == 0) // seg.c:50-57
+    if (need == 0) // scanning the zero prefix (seg.c:50-57)
     {
-      p++;
-      q++;
-      if (p >= 33)
+      const uint32_t lz = win ? (uint32_t)__builtin_clzll(win) : 64u;
+      const uint32_t z = lz < cnt ? lz : cnt;
+      zeros += z;
+      if (zeros >= 33u)
         return ERR_INVALID_FORMAT; // prefix cap: valuesize + 1 (seg.c:55-56,74)
+      drop(z);
+      if (cnt == 0) // ran out inside the prefix
+        return final ? 2 : 0; // seg.c:58-62: EOF inside a (non-empty) zero prefix ends the stream (padding)
+      need = zeros + 1u; // the delimiting one + residual
+      zeros = 0;
     }
-    if (q >= avail) // ran out inside the prefix
-      return final ? 2 : 0; // seg.c:58-62: EOF inside a non-empty zero prefix ends the stream (padding)
-    if (avail - q < (uint64_t)p + 1u)
-      return final ? ERR_LIBRARY_CALL : 0; // EOF inside the residual: a short read in the reference
-    q++; // the delimiting one
-    uint64_t r = 0;
-    for (uint32_t i = 0; i < p; i++)
-      r = (r << 1) | bit(q++);
-    const uint64_t code = (r | ((uint64_t)1 << p)) - 1u; // seg.c:65-66
-    const uint64_t mag = (code + 1u) >> 1;
-    const uint32_t d = (code & 1u) ? (uint32_t)mag : 0u - (uint32_t)mag; // odd code numbers are positive
-    last += d;
-    sample = last;
-    pos = q;
+    if (cnt < need)
+      return final ? ERR_LIBRARY_CALL : 0; // EOF inside the residual is a short read in the reference
+    emit(win >> (64u - need), sample); // (1 << prefix) | residual = code_number + 1 (seg.c:64-66)
+    drop(need);
+    need = 0;
     return 1;
   }
 };

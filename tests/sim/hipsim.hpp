@@ -35,6 +35,20 @@ inline void block_barrier()
   g_block_barrier->arrive_and_wait();
 }
 
+inline uint32_t g_vals[16][64];
+
+inline uint32_t wave_reduce(uint32_t v, bool want_min)
+{
+  const unsigned w = t_threadIdx.x >> 6, l = t_threadIdx.x & 63u;
+  g_vals[w][l] = v;
+  g_wave_barrier[w]->arrive_and_wait();
+  uint32_t r = g_vals[w][0];
+  for (unsigned i = 1; i < 64; i++)
+    r = want_min ? (g_vals[w][i] < r ? g_vals[w][i] : r) : (g_vals[w][i] > r ? g_vals[w][i] : r);
+  g_wave_barrier[w]->arrive_and_wait();
+  return r;
+}
+
 inline bool wave_vote(bool p, bool want_all)
 {
   const unsigned w = t_threadIdx.x >> 6, l = t_threadIdx.x & 63u;
@@ -90,5 +104,13 @@ inline bool wave_any(bool p)
 inline bool wave_all(bool p)
 {
   return sim::wave_vote(p, true);
+}
+inline uint32_t wave_min_u32(uint32_t v)
+{
+  return sim::wave_reduce(v, true);
+}
+inline uint32_t wave_max_u32(uint32_t v)
+{
+  return sim::wave_reduce(v, false);
 }
 } // namespace dg

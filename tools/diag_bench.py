@@ -26,10 +26,25 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         res["cycles_per_wave"] = {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}
         res["total_cycles"] = int(b[:, :8].sum(axis=1).mean())
     print(json.dumps(res))
+    if len(sys.argv) > 4 and sys.argv[4] == "decode":
+        y = torch.zeros((T, C_), dtype=torch.int32, device="cuda"); derr = torch.zeros(C_, dtype=torch.int32, device="cuda")
+        b2 = bits.clone()
+        ctx.profile(True)
+        ctx.decode(out, b2, T, x_tc=y, err=derr)
+        torch.cuda.synchronize()
+        n, ms = ctx.profile_read(1)
+        r2 = {"lib": os.path.basename(dca.LIB_PATH), "decode_kernel_ms": round(ms, 4)}
+        if "diag32" in dca.LIB_PATH:
+            b = b2.cpu().numpy().reshape(-1, 64)
+            names = ["refill", "samples_rest", "short_passes", "code_fast", "code_slow", "wait+copy", "write_rows", "loop_top"]
+            r2["cycles_per_wave"] = {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}
+        else:
+            r2["round_trip_ok"] = bool((y == x).all())
+        print(json.dumps(r2))
 else:
     C_, T = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("65536", "8640")
     libs = [os.path.join(ROOT, "data-compressor_amd", "libdega_hip.so")] + sorted(
         os.path.join(ROOT, "tools", "diag", f) for f in os.listdir(os.path.join(ROOT, "tools", "diag")) if f.endswith(".so"))
     for lib in libs:
         env = dict(os.environ, DEGA_HIP_LIB=lib)
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child", C_, T], env=env)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child", C_, T] + sys.argv[3:], env=env)
