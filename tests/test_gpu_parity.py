@@ -278,3 +278,63 @@ def test_round_trip_large_device_resident(ctx):
     torch.cuda.synchronize()
     assert int((err != 0).sum()) == 0 and int((derr != 0).sum()) == 0
     assert bool((y == x).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json shapes as parity cases
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_cfg3_short_series_high_batch(ctx):
+    """configs[2]: 1 Mi channels x 96 samples (15-min granularity, S = 300).  Every stream round-trips on the device;
+    every 4099th channel is compared byte for byte with the oracle."""
+    import torch
+    Cn, T = 1 << 20, 96
+    x = ctx.synth(Cn, T, seed=1234, S=300)
+    cap = 4 * ((T * 8 + 67) // 4)
+    out, bits, err = ctx.encode(x, adaptive=1, cap=cap)
+    y, derr = ctx.decode(out, bits, T, adaptive=1)
+    torch.cuda.synchronize()
+    assert int((err != 0).sum()) == 0 and int((derr != 0).sum()) == 0
+    assert bool((y == x).all())
+    sel = np.arange(0, Cn, 4099)
+    selt = torch.from_numpy(sel).cuda()
+    want = orc.encode_batch_tc(x[:, selt].cpu().numpy(), 1, cap=cap)
+    assert_streams_equal(out[selt].cpu().numpy(), bits[selt].cpu().numpy().astype(np.uint64), np.zeros(len(sel), dtype=np.int32), *want, tag="cfg3")
+
+
+def test_cfg5_style_streamed_batches(ctx):
+    """configs[4] in miniature: a channel population larger than one resident batch is streamed through the device in
+    batches (here 4 x 32 Ki channels x 1500 samples, generated per batch from the channel ids), encode + decode per
+    batch, and compared with the regenerated input; the concatenation of the batches' bit lengths is checked against
+    one big batch (channels are independent, so the split must not matter)."""
+    import torch
+    per, nb, T = 32768, 4, 1500
+    cap = 4 * ((T * 3 + 67) // 4)
+    all_bits = []
+    for b in range(nb):
+        x = ctx.synth(per, T, seed=1234, c0=b * per, S=50)
+        out, bits, err = ctx.encode(x, adaptive=1, cap=cap)
+        y, derr = ctx.decode(out, bits, T, adaptive=1)
+        torch.cuda.synchronize()
+        assert int((err != 0).sum()) == 0 and int((derr != 0).sum()) == 0 and bool((y == x).all())
+        all_bits.append(bits.clone())
+    xb = ctx.synth(per * nb, T, seed=1234, c0=0, S=50)
+    out, bits, err = ctx.encode(xb, adaptive=1, cap=cap)
+    torch.cuda.synchronize()
+    assert bool((torch.cat(all_bits) == bits).all())
+
+
+def test_static_model_and_float_entry_batch(ctx):
+    """`bac` without `adaptive` (the reference's default) and the float entry, on a batch, vs the oracle."""
+    rng = np.random.default_rng(12)
+    T, Cn = 400, 200
+    v = (np.abs(np.cumsum(rng.normal(0, 0.4, (T, Cn)), axis=0)) + 1.0).astype(np.float32).round(2)
+    for ad in (0, 1):
+        out, bits, err = ctx.encode_f32_host(v, factor=100.0, adaptive=ad)
+        assert (err == 0).all()
+        for c in (0, 63, 64, 199):
+            ret, b, n = orc.encode_f32(np.ascontiguousarray(v[:, c]), 100.0, ad)
+            assert ret == 0 and n == int(bits[c]) and out[c, : len(b)].tobytes() == b
+        back, derr = ctx.decode_f32_host(out, bits, T, factor=100.0, adaptive=ad)
+        ints = np.frombuffer(orc.stage("normalize", True, np.ascontiguousarray(v[:, 0]).tobytes(), T * 32)[1], dtype=">i4")
+        assert (derr == 0).all() and back[:, 0].tobytes() == (ints.astype(np.float32) / np.float32(100.0)).astype(np.float32).tobytes()
