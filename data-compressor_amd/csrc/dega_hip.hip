@@ -103,7 +103,7 @@ extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
   }
   if (hipMemcpy(ctx->div_magic, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
   {
-    hipFree(ctx->div_magic);
+    (void)hipFree(ctx->div_magic);
     delete ctx;
     return DEGA_ERROR_LIBRARY_INIT;
   }
@@ -115,11 +115,11 @@ extern "C" void dega_hip_destroy(dega_hip_ctx *ctx)
 {
   if (ctx == nullptr)
     return;
-  hipSetDevice(ctx->device);
+  (void)hipSetDevice(ctx->device);
   for (int k = 0; k < 2; k++)
     for (hipEvent_t e : ctx->ev[k])
-      hipEventDestroy(e);
-  hipFree(ctx->div_magic);
+      (void)hipEventDestroy(e);
+  (void)hipFree(ctx->div_magic);
   delete ctx;
 }
 
@@ -156,7 +156,7 @@ extern "C" int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_m
   if (reset)
   {
     for (hipEvent_t e : v)
-      hipEventDestroy(e);
+      (void)hipEventDestroy(e);
     v.clear();
   }
   return n;
@@ -175,7 +175,7 @@ struct LaunchTimer
       hipEvent_t e;
       if (hipEventCreate(&e) == hipSuccess)
       {
-        hipEventRecord(e, s);
+        (void)hipEventRecord(e, s);
         ctx->ev[which].push_back(e);
       }
     }
@@ -187,12 +187,12 @@ struct LaunchTimer
       hipEvent_t e;
       if (hipEventCreate(&e) == hipSuccess)
       {
-        hipEventRecord(e, s);
+        (void)hipEventRecord(e, s);
         ctx->ev[which].push_back(e);
       }
       else
       {
-        hipEventDestroy(ctx->ev[which].back());
+        (void)hipEventDestroy(ctx->ev[which].back());
         ctx->ev[which].pop_back();
       }
     }
@@ -415,7 +415,7 @@ struct DevBuf
   ~DevBuf()
   {
     if (p != nullptr)
-      hipFree(p);
+      (void)hipFree(p);
   }
   hipError_t alloc(size_t n)
   {

@@ -147,7 +147,6 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   const size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const bool live = c < a.C;
   uint32_t *const ring_col = &ring[wave * ENC_RING * 64 + lane];
-  const int32_t *const col = a.x + (live ? c : 0);
 
   BacEncoder<ADAPTIVE> enc;
   enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u,
