@@ -58,6 +58,10 @@ int orc_seg_decode(const orc_bits_t *in, orc_bits_t *out, unsigned valuesize);  
 int orc_bac_encode(const orc_bits_t *in, orc_bits_t *out, int adaptive);                           /* bac.c:147-166 */
 int orc_bac_decode(const orc_bits_t *in, orc_bits_t *out, int adaptive);                           /* bac.c:244-263 */
 
+/* LZMH (BASELINE config 4; DCLib/src/lzmh.c:130-574), restated in oracle/lzmh_oracle.c: bytes in -> bit stream out */
+int orc_lzmh_encode(const orc_bits_t *in, orc_bits_t *out);
+int orc_lzmh_decode(const orc_bits_t *in, orc_bits_t *out);
+
 /* Whole-chain helpers on one channel held as native int32 (the chain "encode diff # encode seg # encode bac [adaptive]"
    fed with the channel's samples as big-endian 32-bit values, and its inverse).
    out must hold at least orc_dega_worst_case_bytes(T) bytes.  *out_nbits receives the exact stream length in bits. */

@@ -55,6 +55,8 @@ def lib():
             getattr(L, name).argtypes = [C.POINTER(_Bits), C.POINTER(_Bits), C.c_float, C.c_uint]
         for name in ("orc_diff_encode", "orc_diff_decode", "orc_seg_encode", "orc_seg_decode"):
             getattr(L, name).argtypes = [C.POINTER(_Bits), C.POINTER(_Bits), C.c_uint]
+        for name in ("orc_lzmh_encode", "orc_lzmh_decode"):
+            getattr(L, name).argtypes = [C.POINTER(_Bits), C.POINTER(_Bits)]
         for name in ("orc_bac_encode", "orc_bac_decode"):
             getattr(L, name).argtypes = [C.POINTER(_Bits), C.POINTER(_Bits), C.c_int]
         L.orc_bits_assign.argtypes = [C.POINTER(_Bits), C.c_void_p, C.c_size_t]
@@ -117,6 +119,8 @@ def stage(name, encode, data, nbits, valuesize=32, adaptive=0, factor=100.0):
         return _stage(fn, data, nbits, C.c_float(factor), C.c_uint(valuesize))
     if name == "bac":
         return _stage(fn, data, nbits, C.c_int(adaptive))
+    if name == "lzmh":
+        return _stage(fn, data, nbits)
     return _stage(fn, data, nbits, C.c_uint(valuesize))
 
 

@@ -13,6 +13,8 @@ Fixtures are data only (inputs + the reference's outputs):
   kats.json            known-answer vectors re-generated through the reference library
   channels.npz         small int32 channel batches [T][C] + the reference's per-channel DEGA streams
   floats.npz           float32 edge cases + the reference's normalize / denormalize results
+  lzmh.json / lzmh.npz the reference's `encode lzmh` of the test file (size, bits, sha256) and of small byte strings
+                       (meter CSV text, digits, binary, periodic; lengths around the 403-byte ring size)
 """
 import gzip
 import hashlib
@@ -194,9 +196,57 @@ def floats():
     print("floats:", v.size, "edge rets", rets, "2^31:", ret, b.hex())
 
 
+def lzmh_inputs():
+    """Deterministic byte strings for the LZMH fixtures (name -> bytes)."""
+    rng = np.random.default_rng(11)
+    out = {}
+    for L in (0, 1, 2, 3, 255, 256, 257, 402, 403, 404, 405, 806, 1209):
+        out["digits_%d" % L] = bytes(rng.integers(48, 58, L, dtype=np.uint8))
+    for i, L in enumerate((700, 1500, 4000)):
+        walk = 230.0 + np.cumsum(rng.normal(0, 0.4, L // 7 + 2))
+        out["csv_%d" % L] = "".join("%.2f\n" % v for v in walk).encode()[:L]
+    out["binary_2000"] = bytes(rng.integers(0, 256, 2000, dtype=np.uint8))
+    out["few_symbols_3000"] = bytes(rng.integers(0, 3, 3000, dtype=np.uint8))
+    out["periodic_1000"] = (b"abcabcabd" * 112)[:1000]
+    out["zeros_900"] = bytes(900)
+    out["many_symbols_5000"] = bytes((rng.integers(0, 60, 5000) + 32).astype(np.uint8))
+    return out
+
+
+def lzmh():
+    with open(REF_INPUT, "rb") as f:
+        raw = f.read()
+    data, wrote = dccli(REF_INPUT, ["encode lzmh"])
+    back, _ = dccli(REF_INPUT, ["encode lzmh", "decode lzmh"])
+    meta = {"testfile": {"chain": "encode lzmh", "file_bytes": len(data), "wrote_bytes": wrote[0], "wrote_bits": wrote[1],
+                         "sha256": sha(data), "head": data[:8].hex(), "tail": data[-8:].hex(),
+                         "roundtrip_identical": back == raw}}
+    arrays = {}
+    for name, b in lzmh_inputs().items():
+        ret, s, n, _ = orc.ref_run_chain(b, 8 * len(b), ["encode lzmh"])
+        assert ret == 0, (name, ret)
+        ret2, d, dn, _ = orc.ref_run_chain(s, n, ["decode lzmh"])
+        assert ret2 == 0
+        arrays[name + ".in"] = np.frombuffer(b, dtype=np.uint8).copy()
+        arrays[name + ".stream"] = np.frombuffer(s[: (n + 7) // 8], dtype=np.uint8).copy()
+        arrays[name + ".bits"] = np.array([n], dtype=np.int64)
+        arrays[name + ".dec"] = np.frombuffer(d[: dn // 8], dtype=np.uint8).copy()  # NOT always the input (decoder quirks)
+        meta[name] = {"in_bytes": len(b), "bits": n, "decoded_bytes": dn // 8, "decodes_to_input": d[: dn // 8] == b}
+    with open(os.path.join(HERE, "lzmh.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "lzmh.npz"), **arrays)
+    print("lzmh:", meta["testfile"]["file_bytes"], meta["testfile"]["sha256"][:12],
+          "not round-tripping:", [k for k, v in meta.items() if k != "testfile" and not v["decodes_to_input"]])
+
+
 if __name__ == "__main__":
     assert orc.have_ref() and os.path.exists(orc.REF_CLI), "build oracle/_ref first: make -C oracle"
     testfile()
     kats()
+    only = sys.argv[1:]
+    if only == ["lzmh"]:
+        lzmh()
+        sys.exit(0)
     channels()
     floats()
+    lzmh()
