@@ -51,6 +51,12 @@ _SIGNATURES = {
     "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
     "dega_hip_decode_f32_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P]),
     "dega_hip_decode_f32_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
+    "dega_hip_lzmh_worst_case_bytes": (_Z, [_Z]),
+    "dega_hip_lzmh_encode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P, _P]),
+    "dega_hip_lzmh_decode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P, _P]),
+    "dega_hip_lzmh_render_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, _P, _Z, _P, _P, _P]),
+    "dega_hip_lzmh_encode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P]),
+    "dega_hip_lzmh_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P]),
     "dega_hip_profile": (C.c_int, [_P, C.c_int]),
     "dega_hip_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_int]),
 }
@@ -89,6 +95,10 @@ def exported_symbols():
 
 def worst_case_bytes(T):
     return library().dega_hip_worst_case_bytes(T)
+
+
+def lzmh_worst_case_bytes(n):
+    return library().dega_hip_lzmh_worst_case_bytes(n)
 
 
 class Context:
@@ -194,6 +204,89 @@ class Context:
         packed = torch.empty(max(total, 1), dtype=torch.uint8, device=streams.device)
         self._check(library().dega_hip_compact_gather_dev(self._h, streams.data_ptr(), cap, offsets.data_ptr(), Cn, packed.data_ptr(), self._stream()), "compact_gather")
         return packed[:total], offsets
+
+    # ---- LZMH (BASELINE config 4) ---------------------------------------------------------------------------------
+    def lzmh_encode(self, data, lens, cap=None, out=None, bits=None, err=None):
+        """data: uint8 CUDA tensor [C, stride] (stride % 16 == 0), lens: int64 [C] bytes per channel.
+        Returns (out uint8 [C, cap], bits int64 [C], err int32 [C])."""
+        import torch
+        Cn, stride = data.shape
+        assert data.dtype == torch.uint8 and data.is_cuda and data.is_contiguous() and lens.dtype == torch.int64
+        if cap is None:
+            cap = lzmh_worst_case_bytes(stride)
+        if out is None:
+            out = torch.zeros((Cn, cap), dtype=torch.uint8, device=data.device)
+        if bits is None:
+            bits = torch.zeros(Cn, dtype=torch.int64, device=data.device)
+        if err is None:
+            err = torch.zeros(Cn, dtype=torch.int32, device=data.device)
+        ret = library().dega_hip_lzmh_encode_dev(self._h, data.data_ptr(), stride, lens.data_ptr(), Cn, out.data_ptr(), cap,
+                                                 bits.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_lzmh_encode_dev")
+        return out, bits, err
+
+    def lzmh_decode(self, streams, bits, stride, out=None, lens=None, err=None):
+        """streams: uint8 CUDA tensor [C, cap], bits int64 [C].  Returns (bytes uint8 [C, stride], lens int64 [C], err int32 [C])."""
+        import torch
+        Cn, cap = streams.shape
+        assert streams.dtype == torch.uint8 and streams.is_cuda and streams.is_contiguous() and bits.dtype == torch.int64
+        if out is None:
+            out = torch.zeros((Cn, stride), dtype=torch.uint8, device=streams.device)
+        if lens is None:
+            lens = torch.zeros(Cn, dtype=torch.int64, device=streams.device)
+        if err is None:
+            err = torch.zeros(Cn, dtype=torch.int32, device=streams.device)
+        ret = library().dega_hip_lzmh_decode_dev(self._h, streams.data_ptr(), cap, bits.data_ptr(), Cn, out.data_ptr(), stride,
+                                                 lens.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_lzmh_decode_dev")
+        return out, lens, err
+
+    def lzmh_render(self, x_tc, stride, out=None):
+        """int32 channels [T, C] -> ASCII "%d.%02d\\n" lines per channel: (text uint8 [C, stride], lens int64 [C], err int32 [C])."""
+        import torch
+        T, Cn = x_tc.shape
+        assert x_tc.dtype == torch.int32 and x_tc.is_cuda and x_tc.is_contiguous()
+        if out is None:
+            out = torch.zeros((Cn, stride), dtype=torch.uint8, device=x_tc.device)
+        lens = torch.zeros(Cn, dtype=torch.int64, device=x_tc.device)
+        err = torch.zeros(Cn, dtype=torch.int32, device=x_tc.device)
+        ret = library().dega_hip_lzmh_render_dev(self._h, x_tc.data_ptr(), Cn, T, Cn, out.data_ptr(), stride, lens.data_ptr(),
+                                                 err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_lzmh_render_dev")
+        return out, lens, err
+
+    def lzmh_encode_host(self, strings, cap=None):
+        """strings: list of bytes objects (one per channel).  Returns (out uint8 [C, cap], bits uint64 [C], err int32 [C])."""
+        import numpy as np
+        Cn = len(strings)
+        stride = (max([len(s) for s in strings] + [1]) + 15) // 16 * 16
+        data = np.zeros((Cn, stride), dtype=np.uint8)
+        lens = np.zeros(Cn, dtype=np.uint64)
+        for i, s in enumerate(strings):
+            data[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+            lens[i] = len(s)
+        if cap is None:
+            cap = lzmh_worst_case_bytes(stride)
+        out = np.zeros((Cn, cap), dtype=np.uint8)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_lzmh_encode_host(self._h, data.ctypes.data, stride, lens.ctypes.data, Cn, out.ctypes.data, cap,
+                                                  bits.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_lzmh_encode_host")
+        return out, bits, err
+
+    def lzmh_decode_host(self, streams, bits, stride):
+        import numpy as np
+        streams = np.ascontiguousarray(streams, dtype=np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn, cap = streams.shape
+        out = np.zeros((Cn, stride), dtype=np.uint8)
+        lens = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_lzmh_decode_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, out.ctypes.data, stride,
+                                                  lens.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_lzmh_decode_host")
+        return out, lens, err
 
     def profile(self, enable=True):
         library().dega_hip_profile(self._h, 1 if enable else 0)

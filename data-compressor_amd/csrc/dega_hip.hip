@@ -7,6 +7,7 @@
 
 #include "../../include/dega_hip.h"
 #include "dega_kernels.hpp"
+#include "lzmh_kernels.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,7 +23,7 @@ struct dega_hip_ctx
   uint32_t *div_magic; // device, DIV_TABLE_SIZE entries
   char last_error[256];
   bool profile;
-  std::vector<hipEvent_t> ev[2]; // start/stop pairs per kernel kind (0 encode, 1 decode)
+  std::vector<hipEvent_t> ev[4]; // start/stop pairs per kernel kind (0 encode, 1 decode, 2 lzmh encode, 3 lzmh decode)
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -138,7 +139,7 @@ extern "C" int dega_hip_profile(dega_hip_ctx *ctx, int enable)
 
 extern "C" int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_ms, int reset)
 {
-  if (ctx == nullptr || which < 0 || which > 1 || avg_ms == nullptr)
+  if (ctx == nullptr || which < 0 || which > 3 || avg_ms == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
   std::vector<hipEvent_t> &v = ctx->ev[which];
   double sum = 0.0;
@@ -407,6 +408,72 @@ extern "C" int dega_hip_synth_dev(dega_hip_ctx *ctx, int32_t *x_tc, size_t C, si
   return DEGA_OK;
 }
 
+// ---- LZMH (BASELINE config 4) ----------------------------------------------------------------------------------------
+
+extern "C" size_t dega_hip_lzmh_worst_case_bytes(size_t n)
+{
+  return ((n * 10u + 7u) / 8u + 32u + 15u) / 16u * 16u; // every byte a 10-bit literal + the room the kernel keeps for its last words
+}
+
+static bool aligned16(const void *p)
+{
+  return ((uintptr_t)p & 15u) == 0;
+}
+
+extern "C" int dega_hip_lzmh_encode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out,
+                                        size_t cap, uint64_t *out_bits, int32_t *err, void *stream)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (stride == 0 || (stride & 15u) != 0 || (cap & 15u) != 0 || cap < 48 || stride > 0x7FFFFFF0u || !aligned16(in) || !aligned16(out))
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "lzmh encode: stride/cap must be multiples of 16 (cap >= 48), buffers 16-byte aligned", hipSuccess);
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  LzmhEncodeArgs a{in, stride, in_len, C, out, cap, out_bits, err};
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 2, s);
+    hipLaunchKernelGGL(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_lzmh_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out,
+                                        size_t stride, uint64_t *out_len, int32_t *err, void *stream)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (cap < 4 || (cap & 3u) != 0 || stride < 8 || (stride & 7u) != 0 || ((uintptr_t)in & 3u) != 0 || ((uintptr_t)out & 7u) != 0)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "lzmh decode: cap must be a multiple of 4, stride a multiple of 8", hipSuccess);
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 3, s);
+    hipLaunchKernelGGL(lzmh_decode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_lzmh_render_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, uint8_t *out, size_t stride,
+                                        uint64_t *out_len, int32_t *err, void *stream)
+{
+  if (ctx == nullptr || ld < C || stride < 16 || (stride & 15u) != 0 || !aligned16(out))
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  RenderArgs a{x_tc, C, T, ld, out, stride, out_len, err};
+  hipLaunchKernelGGL(lzmh_render_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
 // ---- host-pointer entry points ---------------------------------------------------------------------------------------
 
 struct DevBuf
@@ -577,6 +644,61 @@ static int decode_f32_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap
     return ret;
   HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(v_tc, dv.p, T * ld * sizeof(float), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_lzmh_encode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out,
+                                         size_t cap, uint64_t *out_bits, int32_t *err)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf din, dlen, dout, dbits, derr;
+  HIP_TRY(ctx, din.alloc(C * stride), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dlen.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(din.p, in, C * stride, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dlen.p, in_len, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
+  int ret;
+  if ((ret = dega_hip_lzmh_encode_dev(ctx, (const uint8_t *)din.p, stride, (const uint64_t *)dlen.p, C, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p,
+                                      (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out,
+                                         size_t stride, uint64_t *out_len, int32_t *err)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf din, dbits, dout, dlen, derr;
+  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * stride), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dlen.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  int ret;
+  if ((ret = dega_hip_lzmh_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, (uint8_t *)dout.p, stride, (uint64_t *)dlen.p,
+                                      (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * stride, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_len, dlen.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }

@@ -1,0 +1,783 @@
+// lzmh_kernels.hpp -- LZMH encode (BASELINE config 4) for gfx950: the reference's second codec, DCLib/src/lzmh.c:130-370.
+//
+// Mapping: one lane = one channel (an independent byte string), one wave = 64 channels, one workgroup = 4 waves.
+// The codec is serial per channel (every code depends on the match window, the recent-offset cache and the frequency
+// list left by the previous one), so -- as for DEGA -- all parallelism is across channels.
+//
+// What the reference does per step, restated without its 403-byte ring (lzmh.c:143-146, 174-191, 343-363): with P
+// bytes consumed so far, look back at most min(P, 128) bytes and ahead at most min(274, min(n, max(P-128, 0) + 403) - P)
+// bytes; take the longest match, the smallest offset among equals (ascending scan with `length > bestlength`, :196-214),
+// code it if it is 3 bytes or longer, else code one literal through the frequency-sorted symbol list.  The ring only
+// shows in those two bounds and in one quirk, kept here: an input of exactly 403 bytes produces no output (:168-174).
+//
+// How a lane searches (the 128-offset scan is ~90% of the reference's time):
+//   phase 1  the lane's last 132 window bytes + the next 24 are read from LDS into registers (38 dwords, one latency),
+//            and a byte-parallel compare marks every position whose first three bytes equal the next three input bytes:
+//            per dword 2 v_alignbyte, 3 xor, or3, a zero-byte test and a multiply that gathers the four flags -- 11
+//            instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
+//   phase 2  candidates are popped nearest first (= ascending offset); one whose byte at the current best length
+//            differs is dropped after one LDS byte read (the reference's own pruning test, :199-200), the others are
+//            measured 16 bytes at a time.
+// Window: 448 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for the whole wave when a lane
+// runs out of look-ahead (every ~300 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count})
+// and four staged output words per lane are in LDS as well: 152 KiB per workgroup, one workgroup per CU.
+//
+// Compiled by hipcc (dega_hip.hip) and, for offline debugging only, by g++ under tests/sim/.
+#pragma once
+
+#include "dega_kernels.hpp"
+
+namespace dg
+{
+
+constexpr uint32_t LZ_HISTORY = 128;    // LZ_MAX_OFFSET, lzmh.c:57
+constexpr uint32_t LZ_MAX_LENGTH = 274; // lzmh.c:61
+constexpr uint32_t LZ_RING = 403;       // INTERN_BUFFER_LENGTH, lzmh.c:64
+constexpr uint32_t LZ_LIST = 48;        // HUFFLIST_LENGTH, lzmh.c:67
+constexpr uint32_t LZ_TREE = 19;        // HUFFTREE_LENGTH, lzmh.c:70
+
+constexpr uint32_t LZ_BLOCK = 256;
+constexpr uint32_t LZ_WIN_DW = 112;              // window dwords per lane (448 bytes)
+constexpr uint32_t LZ_WIN_BYTES = 4 * LZ_WIN_DW;
+constexpr uint32_t LZ_AHEAD = 48;                // look-ahead a step needs in the window: 24 bytes in registers + slack
+constexpr uint32_t LZ_SYM_DW = LZ_LIST / 4, LZ_CNT_DW = LZ_LIST / 2, LZ_STAGE_DW = 4;
+constexpr uint32_t LZ_OFF_WIN = 0, LZ_OFF_SYM = LZ_OFF_WIN + LZ_WIN_DW * LZ_BLOCK, LZ_OFF_CNT = LZ_OFF_SYM + LZ_SYM_DW * LZ_BLOCK,
+                   LZ_OFF_STAGE = LZ_OFF_CNT + LZ_CNT_DW * LZ_BLOCK, LZ_LDS_DW = LZ_OFF_STAGE + LZ_STAGE_DW * LZ_BLOCK;
+static_assert(LZ_LDS_DW * 4 <= 160 * 1024, "LDS budget of one CU");
+
+typedef uint32_t lz_u32x4 __attribute__((vector_size(16)));
+
+struct LzmhEncodeArgs
+{
+  const uint8_t *in;       // [C][stride] bytes, stride a multiple of 16, base 16-byte aligned
+  size_t stride;
+  const uint64_t *in_len;  // [C] bytes per channel, <= stride
+  size_t C;
+  uint8_t *out;            // [C][cap], cap a multiple of 16
+  size_t cap;
+  uint64_t *out_bits;      // [C] exact bit length
+  int32_t *err;            // [C]
+};
+
+DG_DEV uint32_t lz_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) // bytes s..s+3 of the 8 bytes {lo, hi}
+{
+#if defined(DEGA_SIM)
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u)));
+#else
+  return __builtin_amdgcn_alignbyte(hi, lo, s);
+#endif
+}
+
+DG_DEV uint32_t lz_shift_in_nibble(uint32_t acc, uint32_t m) // (acc >> 4) | (m << 28)
+{
+#if defined(DEGA_SIM)
+  return (acc >> 4) | (m << 28);
+#else
+  return __builtin_amdgcn_alignbit(m, acc, 4);
+#endif
+}
+
+// bit 7 of every byte of the result is set where the byte of y is zero; a byte directly above a zero byte may be
+// flagged too when it is 0x01 (borrow) -- callers verify candidates
+DG_DEV uint32_t lz_zero_bytes_approx(uint32_t y)
+{
+  return select32(y, 0u, y - 0x01010101u) & 0x80808080u;
+}
+
+DG_DEV uint32_t lz_zero_bytes_exact(uint32_t y)
+{
+  return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// the four flags (bits 7, 15, 23, 31) gathered into bits 0..3 of the result; bits above are junk
+DG_DEV uint32_t lz_gather_flags(uint32_t f)
+{
+  return mulhi32(f, 0x02040810u);
+}
+
+DG_DEV uint32_t lz_mask_from(int32_t x) // bits x..31 set (x <= 0: all, x >= 32: none)
+{
+  const uint32_t c = (uint32_t)(x < 0 ? 0 : (x > 32 ? 32 : x));
+  return (uint32_t)(0xFFFFFFFFull << c);
+}
+
+// number of equal leading bytes (memory order) of two 16-byte strings held as 4 little-endian dwords, 0..16
+DG_DEV uint32_t lz_common16(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+  const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
+  uint32_t r = 16u;
+  r = x3 != 0 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : r;
+  r = x2 != 0 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : r;
+  r = x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : r;
+  r = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : r;
+  return r;
+}
+
+// the static prefix code of list position p < 19 (lzmh.c:86-106): returns the code, its length in len
+DG_DEV uint32_t lz_list_code(uint32_t p, uint32_t &len)
+{
+  uint32_t code = 0x0Fu - p;
+  len = 4;
+  if (p >= 4)
+  {
+    code = 0x17u - (p - 4u);
+    len = 5;
+  }
+  if (p >= 9)
+  {
+    code = 0x25u - (p - 9u);
+    len = 6;
+  }
+  if (p >= 13)
+  {
+    code = 0x43u - (p - 13u);
+    len = 7;
+  }
+  if (p >= 15)
+  {
+    code = 0x83u - (p - 15u);
+    len = 8;
+  }
+  return code;
+}
+
+__global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a)
+{
+  __shared__ uint32_t lds[LZ_LDS_DW];
+  const uint32_t tid = threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + tid;
+  const bool live = c < a.C;
+  uint32_t *const win = lds + LZ_OFF_WIN + tid;                                  // dword d of this lane: win[d * LZ_BLOCK]
+  uint8_t *const win8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_WIN + tid);     // byte b: win8[(b >> 2) * 4 * LZ_BLOCK + (b & 3)]
+  uint32_t *const symd = lds + LZ_OFF_SYM + tid;
+  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_SYM + tid);
+  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZ_OFF_CNT + tid);  // count i: cnt16[(i >> 1) * 2 * LZ_BLOCK + (i & 1)]
+  uint32_t *const stage = lds + LZ_OFF_STAGE + tid;
+#define LZ_WIN8(b) win8[((b) >> 2) * (4u * LZ_BLOCK) + ((b) & 3u)]
+#define LZ_SYM8(i) sym8[((i) >> 2) * (4u * LZ_BLOCK) + ((i) & 3u)]
+#define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
+
+  const uint64_t n64 = live ? a.in_len[c] : 0;
+  const uint32_t n = (uint32_t)n64;
+  const uint8_t *const src = a.in + (live ? c : 0) * a.stride;
+  uint8_t *const dst = a.out + (live ? c : 0) * a.cap;
+  int32_t err = (n64 > a.stride || n64 > 0x7FFFFFF0ull) ? ERR_INVALID_VALUE : OK;
+  // lzmh.c:161-174: exactly one ring of input wraps the write index onto the read index and the main loop never runs
+  const uint32_t n_eff = (n == LZ_RING || err != OK) ? 0u : n;
+
+  uint32_t P = 0;          // bytes consumed
+  int32_t base = -128;     // absolute position of window byte 0 (multiple of 16)
+  uint32_t mru = 0;        // the four most recent offsets, most recent in the low byte (lzmh.c:135)
+  uint32_t nlist = 0;      // used entries of the frequency list
+  uint64_t acc = 0;        // output bits, MSB first
+  uint32_t nacc = 0, staged = 0, pos = 0; // bits in acc, words in stage[], words stored
+  bool reload = true;
+
+  for (;;)
+  {
+    const bool active = P < n_eff && err == OK;
+    if (!wave_any(active))
+      break;
+
+    // ---- window: every active lane of the wave reloads [P-128 (rounded down to 16), +448) when one lane needs it ----
+    if (wave_any(active && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
+    {
+      if (active)
+      {
+        base = (int32_t)((P - LZ_HISTORY) & ~15u);
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_WIN_DW / 4; k++)
+        {
+          const int32_t at = base + (int32_t)(16u * k);
+          uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+          if (at >= 0 && (size_t)at + 16u <= a.stride)
+          {
+            const lz_u32x4 v = *reinterpret_cast<const lz_u32x4 *>(src + at);
+            v0 = v[0];
+            v1 = v[1];
+            v2 = v[2];
+            v3 = v[3];
+          }
+          win[(4u * k + 0u) * LZ_BLOCK] = v0;
+          win[(4u * k + 1u) * LZ_BLOCK] = v1;
+          win[(4u * k + 2u) * LZ_BLOCK] = v2;
+          win[(4u * k + 3u) * LZ_BLOCK] = v3;
+        }
+      }
+      reload = false;
+    }
+
+    // ---- bounds of this step (see the header) ----
+    const uint32_t maxoff = P < LZ_HISTORY ? P : LZ_HISTORY;
+    const uint32_t wabs_raw = (P > LZ_HISTORY ? P - LZ_HISTORY : 0u) + LZ_RING;
+    const uint32_t wabs = wabs_raw < n ? wabs_raw : n;
+    uint32_t maxlen = wabs - P;
+    maxlen = maxlen > LZ_MAX_LENGTH ? LZ_MAX_LENGTH : maxlen;
+    const uint32_t in_window = (uint32_t)(base + (int32_t)LZ_WIN_BYTES - (int32_t)P); // bytes of look-ahead the window holds
+    const uint32_t lim = maxlen < in_window ? maxlen : in_window;
+    const bool search = active && maxoff > 0 && maxlen > 2;
+
+    // ---- phase 1: 3-byte candidates among the last 132 positions ----
+    const uint32_t rel = active ? (uint32_t)((int32_t)P - base) : LZ_HISTORY; // window byte index of position P (128..400)
+    const uint32_t wd0 = (rel - LZ_HISTORY) >> 2;                             // first history dword
+    const uint32_t s = rel & 3u;
+    uint32_t d[38];
+#pragma unroll
+    for (uint32_t j = 0; j < 38; j++)
+      d[j] = win[(wd0 + j) * LZ_BLOCK];
+    const uint32_t T0 = lz_alignbyte(d[33], d[32], s), T1 = lz_alignbyte(d[34], d[33], s), T2 = lz_alignbyte(d[35], d[34], s),
+                   T3 = lz_alignbyte(d[36], d[35], s);
+    const uint32_t A0 = (T0 & 0xFFu) * 0x01010101u, A1 = ((T0 >> 8) & 0xFFu) * 0x01010101u, A2 = ((T0 >> 16) & 0xFFu) * 0x01010101u;
+    uint32_t cm[5] = {0, 0, 0, 0, 0}; // bit i of the 132-bit mask: window position 4*wd0 + i starts a 3-byte match
+#pragma unroll
+    for (uint32_t j = 0; j < 33; j++)
+    {
+      const uint32_t y = (d[j] ^ A0) | (lz_alignbyte(d[j + 1], d[j], 1) ^ A1) | (lz_alignbyte(d[j + 1], d[j], 2) ^ A2);
+      cm[j >> 3] = lz_shift_in_nibble(cm[j >> 3], lz_gather_flags(lz_zero_bytes_approx(y)));
+    }
+    cm[4] >>= 28;
+    {
+      // position i is offset 128 + s - i: valid offsets are 1..maxoff
+      const int32_t lo = (int32_t)(LZ_HISTORY + s - maxoff);
+      const uint32_t keep = search ? 0xFFFFFFFFu : 0u;
+      cm[0] &= lz_mask_from(lo) & keep;
+      cm[1] &= lz_mask_from(lo - 32) & keep;
+      cm[2] &= lz_mask_from(lo - 64) & keep;
+      cm[3] &= lz_mask_from(lo - 96) & keep;
+      cm[4] &= ((1u << s) - 1u) & keep;
+    }
+
+    // ---- phase 2: nearest candidate first; measure it unless its byte at the best length so far already differs ----
+    uint32_t best = 2, besto = 0;
+#pragma unroll
+    for (int r = 4; r >= 0; r--)
+    {
+      while (wave_any(cm[r] != 0 && best < lim))
+      {
+        if (cm[r] != 0 && best < lim)
+        {
+          const uint32_t bit = 31u - clz32(cm[r]);
+          cm[r] &= ~(1u << bit);
+          const uint32_t i = 32u * (uint32_t)r + bit;
+          const uint32_t qb = 4u * wd0 + i; // window byte index of the candidate
+          if (LZ_WIN8(qb + best) == LZ_WIN8(rel + best))
+          {
+            const uint32_t qd = qb >> 2, qs = qb & 3u;
+            const uint32_t e0 = win[(qd + 0u) * LZ_BLOCK], e1 = win[(qd + 1u) * LZ_BLOCK], e2 = win[(qd + 2u) * LZ_BLOCK],
+                           e3 = win[(qd + 3u) * LZ_BLOCK], e4 = win[(qd + 4u) * LZ_BLOCK];
+            uint32_t len = lz_common16(lz_alignbyte(e1, e0, qs), lz_alignbyte(e2, e1, qs), lz_alignbyte(e3, e2, qs),
+                                       lz_alignbyte(e4, e3, qs), T0, T1, T2, T3);
+            if (len == 16u)
+              while (len < lim && LZ_WIN8(qb + len) == LZ_WIN8(rel + len))
+                len++;
+            len = len < lim ? len : lim;
+            if (len > best)
+            {
+              best = len;
+              besto = LZ_HISTORY + s - i;
+            }
+          }
+        }
+      }
+    }
+    // a match that ran into the end of the window before the reference's own limit: reload around P and do the step again
+    const bool again = search && best >= lim && lim < maxlen;
+    if (again)
+      reload = true;
+    const bool emit = active && !again;
+
+    // ---- code the step (lzmh.c:216-340) ----
+    uint32_t code = 0, codelen = 0;
+    const bool lit = emit && best < 3;
+    if (emit && best >= 3)
+    {
+      const uint32_t o0 = mru & 0xFFu, o1 = (mru >> 8) & 0xFFu, o2 = (mru >> 16) & 0xFFu, o3 = mru >> 24;
+      if (o0 == besto)
+      {
+        code = 0x06u;
+        codelen = 4;
+      }
+      else if (o1 == besto)
+      {
+        code = 0x0Eu;
+        codelen = 5;
+        mru = (mru & 0xFFFF0000u) | (o0 << 8) | besto;
+      }
+      else if (o2 == besto)
+      {
+        code = 0x1Eu;
+        codelen = 6;
+        mru = (mru & 0xFF000000u) | ((mru & 0xFFFFu) << 8) | besto;
+      }
+      else if (o3 == besto)
+      {
+        code = 0x1Fu;
+        codelen = 6;
+        mru = (mru << 8) | besto;
+      }
+      else
+      {
+        code = 0x100u | (besto - 1u);
+        codelen = 10;
+        mru = (mru << 8) | besto;
+      }
+      if (best < 11)
+      {
+        code = (code << 4) | (best - 3u);
+        codelen += 4;
+      }
+      else if (best < 19)
+      {
+        code = (code << 5) | 0x10u | (best - 11u);
+        codelen += 5;
+      }
+      else
+      {
+        code = (code << 10) | 0x300u | (best - 19u);
+        codelen += 10;
+      }
+      P += best;
+    }
+    if (wave_any(lit))
+    {
+      // literal: position of the symbol in the frequency list (lzmh.c:285-333)
+      const uint32_t sym = T0 & 0xFFu, splat = sym * 0x01010101u;
+      uint32_t found = 0xFFFFu;
+#pragma unroll
+      for (uint32_t g = 0; g < LZ_SYM_DW / 4; g++)
+      {
+        if (!wave_any(lit && found == 0xFFFFu && 16u * g < nlist))
+          break;
+#pragma unroll
+        for (uint32_t k = 4 * g + 3; k + 1 > 4 * g; k--)
+        {
+          const uint32_t z = lz_zero_bytes_exact(symd[k * LZ_BLOCK] ^ splat);
+          if (z != 0 && 16u * g < nlist)
+          {
+            const uint32_t p = 4u * k + ((uint32_t)__builtin_ctz(z) >> 3);
+            found = (p < nlist && p < found) ? p : found; // entries at and above nlist hold stale bytes
+          }
+        }
+      }
+      if (lit)
+      {
+        if (found != 0xFFFFu)
+        {
+          const uint32_t c0 = LZ_CNT(found);
+          if (c0 < 65535u)
+          {
+            uint32_t i = found; // bubble towards the front past entries with a smaller count: only symbols move (:306-309)
+            while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+            {
+              LZ_SYM8(i) = LZ_SYM8(i - 1u);
+              i--;
+            }
+            LZ_CNT(i) = (uint16_t)(c0 + 1u);
+            LZ_SYM8(i) = (uint8_t)sym;
+          }
+        }
+        else if (nlist < LZ_LIST)
+        {
+          LZ_SYM8(nlist) = (uint8_t)sym;
+          LZ_CNT(nlist) = 1;
+          nlist++;
+        }
+        if (found < LZ_TREE)
+          code = lz_list_code(found, codelen);
+        else
+        {
+          code = sym; // 00 + byte
+          codelen = 10;
+        }
+        P += 1;
+      }
+    }
+
+    // ---- output: bits -> 64-bit accumulator -> staged words in LDS -> 16-byte stores ----
+    if (emit)
+    {
+      acc |= (uint64_t)code << (64u - nacc - codelen);
+      nacc += codelen;
+    }
+    if (nacc >= 32u)
+    {
+      stage[staged * LZ_BLOCK] = (uint32_t)(acc >> 32);
+      staged++;
+      acc <<= 32;
+      nacc -= 32u;
+    }
+    if (wave_any(staged == LZ_STAGE_DW))
+    {
+      if (staged == LZ_STAGE_DW)
+      {
+        if ((size_t)pos * 4u + 32u > a.cap) // keep room for the last words of finish
+          err = ERR_MEMORY;
+        else
+        {
+          const lz_u32x4 v = {bswap32(stage[0 * LZ_BLOCK]), bswap32(stage[1 * LZ_BLOCK]), bswap32(stage[2 * LZ_BLOCK]),
+                              bswap32(stage[3 * LZ_BLOCK])};
+          *reinterpret_cast<lz_u32x4 *>(dst + (size_t)pos * 4u) = v;
+          pos += LZ_STAGE_DW;
+        }
+        staged = 0;
+      }
+    }
+  }
+
+  // ---- finish: the staged words and the partial word, zero padded ----
+  if (live)
+  {
+    uint64_t bits = 0;
+    if (err == OK)
+    {
+      if ((size_t)(pos + staged + 1u) * 4u > a.cap)
+        err = ERR_MEMORY;
+      else
+      {
+        for (uint32_t k = 0; k < staged; k++)
+          *reinterpret_cast<uint32_t *>(dst + (size_t)(pos + k) * 4u) = bswap32(stage[k * LZ_BLOCK]);
+        if (nacc > 0)
+          *reinterpret_cast<uint32_t *>(dst + (size_t)(pos + staged) * 4u) = bswap32((uint32_t)(acc >> 32));
+        bits = 32ull * (pos + staged) + nacc;
+      }
+    }
+    a.out_bits[c] = bits;
+    a.err[c] = err;
+  }
+#undef LZ_WIN8
+#undef LZ_SYM8
+#undef LZ_CNT
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LZMH decode (DCLib/src/lzmh.c:383-574), one lane per channel.  The decoder is a 32-bit code register that is topped up
+// to 25 bits and consumed from the top (:410-415), a 128-byte history ring (:396) and the same frequency list; it is
+// restated literally, including what it does at the end of a stream: it keeps decoding while the register holds a set
+// bit (:571) and stops silently on an unknown list code (:447-449).  List entries that were never written read as symbol
+// 0 here (the reference reads uninitialised stack there).
+constexpr uint32_t LZD_HIST_DW = LZ_HISTORY / 4;
+constexpr uint32_t LZD_OFF_HIST = 0, LZD_OFF_SYM = LZD_OFF_HIST + LZD_HIST_DW * LZ_BLOCK, LZD_OFF_CNT = LZD_OFF_SYM + LZ_SYM_DW * LZ_BLOCK,
+                   LZD_LDS_DW = LZD_OFF_CNT + LZ_CNT_DW * LZ_BLOCK;
+
+struct LzmhDecodeArgs
+{
+  const uint8_t *in;       // [C][cap] streams (32-bit big-endian words), cap a multiple of 4
+  size_t cap;
+  const uint64_t *in_bits; // [C]
+  size_t C;
+  uint8_t *out;            // [C][stride] decoded bytes, stride a multiple of 8
+  size_t stride;
+  uint64_t *out_len;       // [C]
+  int32_t *err;            // [C]
+};
+
+__global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a)
+{
+  __shared__ uint32_t lds[LZD_LDS_DW];
+  const uint32_t tid = threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + tid;
+  uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + tid);
+  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_SYM + tid);
+  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZD_OFF_CNT + tid);
+#define LZ_HIST8(b) hist8[((b) >> 2) * (4u * LZ_BLOCK) + ((b) & 3u)]
+#define LZ_SYM8(i) sym8[((i) >> 2) * (4u * LZ_BLOCK) + ((i) & 3u)]
+#define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
+  for (uint32_t k = 0; k < LZD_LDS_DW / LZ_BLOCK; k++)
+    lds[k * LZ_BLOCK + tid] = 0;
+  if (c >= a.C)
+    return;
+
+  const uint64_t nbits = a.in_bits[c];
+  const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + c * a.cap);
+  uint8_t *const dst = a.out + c * a.stride;
+  const uint32_t last_word = a.cap >= 4 ? (uint32_t)(a.cap / 4 - 1) : 0;
+  int32_t err = (nbits > 8ull * a.cap || a.cap < 4) ? ERR_INVALID_VALUE : OK;
+
+  uint64_t ip = 0;            // next input bit
+  uint32_t wi = 0;            // index of w0
+  uint32_t w0 = 0, w1 = 0, w2 = 0; // stream words wi, wi+1, wi+2 (w2 is the one in flight)
+  if (err == OK)
+  {
+    w0 = bswap32(src[0]);
+    w1 = bswap32(src[1 < last_word ? 1 : last_word]);
+    w2 = bswap32(src[2 < last_word ? 2 : last_word]);
+  }
+  uint32_t code_sym = 0;
+  int32_t code_length = 0;
+  uint32_t hp = 0, mru = 0;
+  uint64_t obuf = 0;
+  uint32_t nob = 0;
+  uint64_t olen = 0;
+
+  // one decoded byte: history ring + 8-byte output accumulator
+#define LZ_EMIT(b)                                                  \
+  do                                                                \
+  {                                                                 \
+    const uint32_t b_ = (b);                                        \
+    LZ_HIST8(hp) = (uint8_t)b_;                                     \
+    hp = (hp + 1u) & (LZ_HISTORY - 1u);                             \
+    obuf |= (uint64_t)b_ << (8u * nob);                             \
+    if (++nob == 8u)                                                \
+    {                                                               \
+      if (olen + 8u > a.stride)                                     \
+        err = ERR_MEMORY;                                           \
+      else                                                          \
+        *reinterpret_cast<uint64_t *>(dst + olen) = obuf;           \
+      olen += 8;                                                    \
+      obuf = 0;                                                     \
+      nob = 0;                                                      \
+    }                                                               \
+  } while (0)
+
+  if (err == OK)
+    do
+    {
+      // ---- top the register up to 25 bits (lzmh.c:410-415); bits shifted in while code_length <= 0 fall off ----
+      while (ip < nbits && code_length <= 24)
+      {
+        const uint64_t avail = nbits - ip;
+        uint32_t k;
+        bool lost = false;
+        if (code_length < 0)
+        {
+          k = (uint32_t)(-code_length);
+          lost = true;
+        }
+        else
+          k = 25u - (uint32_t)code_length;
+        k = avail < k ? (uint32_t)avail : k;
+        const uint32_t sh = (uint32_t)(ip & 31u);
+        const uint64_t two = ((uint64_t)w0 << 32) | w1;
+        const uint32_t chunk = (uint32_t)((two << sh) >> (64u - k)); // k in 1..25
+        if (!lost)
+          code_sym |= chunk << (32u - (uint32_t)code_length - k);
+        code_length += (int32_t)k;
+        ip += k;
+        const uint32_t nwi = (uint32_t)(ip >> 5);
+        if (nwi != wi)
+        {
+          wi = nwi;
+          w0 = w1;
+          w1 = w2;
+          const uint32_t idx = wi + 2u;
+          w2 = bswap32(src[idx < last_word ? idx : last_word]);
+        }
+      }
+      if ((code_sym & 0x80000000u) != 0) // list code
+      {
+        uint32_t i = LZ_TREE, len = 0;
+        for (uint32_t p = 0; p < LZ_TREE; p++)
+        {
+          uint32_t l;
+          const uint32_t code = lz_list_code(p, l);
+          if (code_length >= (int32_t)l && (code_sym >> (32u - l)) == code)
+          {
+            i = p;
+            len = l;
+            break;
+          }
+        }
+        if (i == LZ_TREE)
+          break; // unknown code: the reference returns NO_ERROR here
+        const uint32_t sym = LZ_SYM8(i);
+        code_length -= (int32_t)len;
+        code_sym <<= len;
+        LZ_EMIT(sym);
+        const uint32_t c0 = LZ_CNT(i);
+        if (c0 < 65535u)
+        {
+          while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+          {
+            LZ_SYM8(i) = LZ_SYM8(i - 1u);
+            i--;
+          }
+          LZ_CNT(i) = (uint16_t)(c0 + 1u);
+          LZ_SYM8(i) = (uint8_t)sym;
+        }
+      }
+      else if ((code_sym & 0x40000000u) == 0) // 00 + byte
+      {
+        const uint32_t sym = (code_sym >> 22) & 0xFFu;
+        code_length -= 10;
+        code_sym <<= 10;
+        LZ_EMIT(sym);
+        uint32_t i = 0;
+        while (i < LZ_LIST && LZ_CNT(i) > 0 && LZ_SYM8(i) != sym)
+          i++;
+        if (i < LZ_LIST)
+        {
+          const uint32_t c0 = LZ_CNT(i);
+          if (c0 < 65535u)
+          {
+            while (i > 0 && c0 + 1u > LZ_CNT(i - 1u)) // whole entries move here (:470-474)
+            {
+              LZ_SYM8(i) = LZ_SYM8(i - 1u);
+              LZ_CNT(i) = LZ_CNT(i - 1u);
+              i--;
+            }
+            LZ_CNT(i) = (uint16_t)(c0 + 1u);
+            LZ_SYM8(i) = (uint8_t)sym;
+          }
+        }
+      }
+      else // match
+      {
+        uint32_t offset, length;
+        code_length -= 2;
+        code_sym <<= 2;
+        if ((code_sym & 0x80000000u) == 0)
+        {
+          offset = ((code_sym >> 24) & 0x7Fu) + 1u;
+          code_length -= 8;
+          code_sym <<= 8;
+          mru = (mru << 8) | offset;
+        }
+        else
+        {
+          code_length -= 1;
+          code_sym <<= 1;
+          if ((code_sym & 0x80000000u) == 0)
+            offset = mru & 0xFFu;
+          else
+          {
+            code_length -= 1;
+            code_sym <<= 1;
+            if ((code_sym & 0x80000000u) == 0)
+            {
+              offset = (mru >> 8) & 0xFFu;
+              mru = (mru & 0xFFFF0000u) | ((mru & 0xFFu) << 8) | offset;
+            }
+            else
+            {
+              code_length -= 1;
+              code_sym <<= 1;
+              if ((code_sym & 0x80000000u) == 0)
+              {
+                offset = (mru >> 16) & 0xFFu;
+                mru = (mru & 0xFF000000u) | ((mru & 0xFFFFu) << 8) | offset;
+              }
+              else
+              {
+                offset = mru >> 24;
+                mru = (mru << 8) | offset;
+              }
+            }
+          }
+          code_length -= 1;
+          code_sym <<= 1;
+        }
+        if ((code_sym & 0x80000000u) == 0)
+        {
+          length = ((code_sym >> 28) & 7u) + 3u;
+          code_length -= 4;
+          code_sym <<= 4;
+        }
+        else
+        {
+          code_length -= 1;
+          code_sym <<= 1;
+          if ((code_sym & 0x80000000u) == 0)
+          {
+            length = ((code_sym >> 28) & 7u) + 11u;
+            code_length -= 4;
+            code_sym <<= 4;
+          }
+          else
+          {
+            length = ((code_sym >> 23) & 0xFFu) + 19u;
+            code_length -= 9;
+            code_sym <<= 9;
+          }
+        }
+        for (uint32_t k = 0; k < length && err == OK; k++)
+        {
+          const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
+          LZ_EMIT(sym);
+        }
+      }
+    } while (err == OK && (ip < nbits || code_sym > 0));
+
+  if (err == OK && nob > 0)
+  {
+    if (olen + 8u > a.stride)
+      err = ERR_MEMORY;
+    else
+      *reinterpret_cast<uint64_t *>(dst + olen) = obuf;
+    olen += nob;
+  }
+  a.out_len[c] = err == OK ? olen : 0;
+  a.err[c] = err;
+#undef LZ_EMIT
+#undef LZ_HIST8
+#undef LZ_SYM8
+#undef LZ_CNT
+}
+
+// ASCII rendering of the synthetic meter channels for the LZMH workload (cfg 4): channel c's samples
+// x[t][c] (centi-units) as "%d.%02d\n" lines -- the "ASCII float in" domain of the reference's LZMH (DCLib/doc/readme.md:30).
+struct RenderArgs
+{
+  const int32_t *x; // [T][ld]
+  size_t C, T, ld;
+  uint8_t *out;     // [C][stride]
+  size_t stride;
+  uint64_t *out_len; // [C]
+  int32_t *err;      // [C]: ERR_MEMORY when a channel's text does not fit
+};
+
+__global__ void __launch_bounds__(256) lzmh_render_kernel(const RenderArgs a)
+{
+  const size_t c = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (c >= a.C)
+    return;
+  uint8_t *const dst = a.out + c * a.stride;
+  size_t len = 0;
+  int32_t err = OK;
+  uint64_t acc = 0; // up to 8 pending bytes, first byte lowest
+  uint32_t nacc = 0;
+  for (size_t t = 0; t < a.T; t++)
+  {
+    const int32_t v = a.x[t * a.ld + c];
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    uint8_t txt[16];
+    uint32_t k = 0;
+    txt[k++] = '\n';
+    txt[k++] = (uint8_t)('0' + u % 10u);
+    u /= 10u;
+    txt[k++] = (uint8_t)('0' + u % 10u);
+    u /= 10u;
+    txt[k++] = '.';
+    do
+    {
+      txt[k++] = (uint8_t)('0' + u % 10u);
+      u /= 10u;
+    } while (u != 0);
+    if (v < 0)
+      txt[k++] = '-';
+    if (len + nacc + k + 8u > a.stride)
+    {
+      err = ERR_MEMORY;
+      break;
+    }
+    while (k > 0)
+    {
+      acc |= (uint64_t)txt[--k] << (8u * nacc);
+      if (++nacc == 8u)
+      {
+        *reinterpret_cast<uint64_t *>(dst + len) = acc;
+        len += 8;
+        acc = 0;
+        nacc = 0;
+      }
+    }
+  }
+  if (err == OK && nacc > 0)
+  {
+    *reinterpret_cast<uint64_t *>(dst + len) = acc;
+    len += nacc;
+  }
+  a.out_len[c] = err == OK ? len : 0;
+  a.err[c] = err;
+}
+
+} // namespace dg

@@ -69,5 +69,6 @@ int SetOptionValueChar(options_t *options, const char *name, char value);
 enc_dec_function_t CopyBits;                       /* "copy": plumbing / tests, no GPU */
 enc_dec_function_t EncodeDEGA, DecodeDEGA;         /* "dega":  big-endian int32 values <-> DEGA stream (GPU) */
 enc_dec_function_t EncodeDEGAFloat, DecodeDEGAFloat; /* "fdega": raw float32 <-> DEGA stream, normalize fused (GPU) */
+enc_dec_function_t EncodeLZMHGPU, DecodeLZMHGPU;   /* "glzmh": bytes <-> the reference's LZMH stream (GPU) */
 
 #endif

@@ -9,6 +9,9 @@
  *            decode: the inverse (`decode bac [adaptive] # decode seg # decode diff`)
  *   "fdega"  the same with normalize / denormalize fused in: raw float32 in or out (what `decode csv` emits / `encode csv` eats)
  *
+ *   "glzmh"  the reference's second codec on the GPU: bytes in -> the stream `encode lzmh` produces, bit for bit, and
+ *            its inverse (DCLib/src/lzmh.c:130-574).  Named so that it does not extend "lzmh" (prefix lookup).
+ *
  * Contract kept: consume the input until EndOfBitFileBuffer, write all output with Write*, never
  * flush/close/free either buffer, return NO_ERROR or a negative code and log to options->error_log_file.
  * The work itself happens on the GPU; without one the codec fails with ERROR_LIBRARY_INIT -- there is no CPU path here.
@@ -403,4 +406,106 @@ io_int_t DecodeDEGA(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *cons
 io_int_t DecodeDEGAFloat(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *const out_bit_buf, const options_t *const options)
 {
   return decode_common(in_bit_buf, out_bit_buf, options, 1);
+}
+
+/* ---- LZMH on the GPU ("glzmh") ----------------------------------------------------------------------------------------- */
+
+io_int_t EncodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *const out_bit_buf, const options_t *const options)
+{
+  FILE *const log = options->error_log_file;
+  dega_hip_ctx *ctx;
+  byte_vec raw = { NULL, 0, 0 };
+  uint64_t nbits = 0, in_len, out_bits = 0;
+  uint8_t *in = NULL, *out = NULL;
+  int32_t err = 0;
+  size_t stride, cap;
+  io_int_t ret;
+
+  if ((ret = get_context(log, &ctx)) != NO_ERROR)
+    return ret;
+  if ((ret = slurp(in_bit_buf, &raw, &nbits)) != NO_ERROR)
+    goto done;
+  if (nbits % 8 != 0) /* the reference's READ_VALUE_BITS_CHECKED(8) would stop on the short last byte (lzmh.c:163) */
+  {
+    LOG_TO(log, "Only read %lu bits instead of 8\n", (unsigned long)(nbits % 8));
+    ret = ERROR_LIBRARY_CALL;
+    goto done;
+  }
+  in_len = nbits / 8;
+  stride = ((size_t)in_len + 16) / 16 * 16;
+  cap = dega_hip_lzmh_worst_case_bytes(stride);
+  if (posix_memalign((void **)&in, 16, stride) != 0 || posix_memalign((void **)&out, 16, cap) != 0)
+  {
+    ret = ERROR_MEMORY;
+    goto done;
+  }
+  memset(in, 0, stride);
+  memcpy(in, raw.p, (size_t)in_len);
+  if ((ret = dega_hip_lzmh_encode_host(ctx, in, stride, &in_len, 1, out, cap, &out_bits, &err)) != DEGA_OK)
+  {
+    LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_last_error(ctx));
+    goto done;
+  }
+  if ((ret = first_error(&err, 1, log, "encoding")) != NO_ERROR)
+    goto done;
+  if (WriteBitFileBuffer(out_bit_buf, out, (size_t)out_bits) != (io_int_t)out_bits)
+    ret = ERROR_LIBRARY_CALL;
+done:
+  free(raw.p);
+  free(in);
+  free(out);
+  return ret;
+}
+
+io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *const out_bit_buf, const options_t *const options)
+{
+  FILE *const log = options->error_log_file;
+  dega_hip_ctx *ctx;
+  byte_vec raw = { NULL, 0, 0 };
+  uint64_t nbits = 0, out_len = 0;
+  uint8_t *in = NULL, *out = NULL;
+  int32_t err = 0;
+  size_t cap, stride;
+  int attempt;
+  io_int_t ret;
+
+  if ((ret = get_context(log, &ctx)) != NO_ERROR)
+    return ret;
+  if ((ret = slurp(in_bit_buf, &raw, &nbits)) != NO_ERROR)
+    goto done;
+  cap = (raw.n + 8) / 4 * 4;
+  if ((in = (uint8_t *)calloc(cap, 1)) == NULL)
+  {
+    ret = ERROR_MEMORY;
+    goto done;
+  }
+  memcpy(in, raw.p, raw.n);
+  /* a bare LZMH stream does not say how long its text is: start from 4x and grow while the row overflows */
+  stride = (4 * raw.n + 4096) / 8 * 8;
+  for (attempt = 0;; attempt++)
+  {
+    free(out);
+    if ((out = (uint8_t *)malloc(stride)) == NULL)
+    {
+      ret = ERROR_MEMORY;
+      goto done;
+    }
+    if ((ret = dega_hip_lzmh_decode_host(ctx, in, cap, &nbits, 1, out, stride, &out_len, &err)) != DEGA_OK)
+    {
+      LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_last_error(ctx));
+      goto done;
+    }
+    if (err != ERROR_MEMORY || attempt == 5)
+      break;
+    stride *= 8;
+  }
+  if ((ret = first_error(&err, 1, log, "decoding")) != NO_ERROR)
+    goto done;
+  if (WriteBitFileBuffer(out_bit_buf, out, (size_t)out_len * 8) != (io_int_t)(out_len * 8))
+    ret = ERROR_LIBRARY_CALL;
+done:
+  free(raw.p);
+  free(in);
+  free(out);
+  return ret;
 }

@@ -49,6 +49,7 @@ static const codec_row_t codecs[] = { /* sorted by name */
   { "copy", "Copies input to output", { &CopyBits, &CopyBits }, OPT_BLOCKSIZE },
   { "dega", "diff + seg + bac on the GPU (MI355X), big-endian integer values in", { &EncodeDEGA, &DecodeDEGA }, OPT_ADAPTIVE | OPT_VALUESIZE | OPT_NUM_CHANNELS },
   { "fdega", "normalize + diff + seg + bac on the GPU (MI355X), raw floats in", { &EncodeDEGAFloat, &DecodeDEGAFloat }, OPT_ADAPTIVE | OPT_VALUESIZE | OPT_NORMALIZATION | OPT_NUM_CHANNELS },
+  { "glzmh", "LZMH on the GPU (MI355X): the stream of the reference's lzmh, bit for bit", { &EncodeLZMHGPU, &DecodeLZMHGPU }, 0 },
 };
 static const size_t num_codecs = sizeof(codecs) / sizeof(codecs[0]);
 

@@ -94,6 +94,28 @@ int dega_hip_compact_gather_dev(dega_hip_ctx *ctx, const uint8_t *slabs, size_t 
    c0 (so that rank r of a multi-GPU job generates its own channel range). */
 int dega_hip_synth_dev(dega_hip_ctx *ctx, int32_t *x_tc, size_t C, size_t T, size_t ld, uint64_t seed, uint64_t c0, uint32_t S, void *stream);
 
+/* ---- LZMH, the reference's second codec (BASELINE config 4) ------------------------------------------------------- */
+/* Replaces EncodeLZMH (DCLib/src/lzmh.c:130-370) and DecodeLZMH (:383-574), table row "lzmh" (DCLib/src/enc_dec.c:51-60),
+   per channel and bit for bit, including the codec's quirks (an input of exactly 403 bytes encodes to nothing, :161-174;
+   the decoder stops once its code register is empty after the last input bit, :571).  One GPU lane per channel.
+   encode: in = uint8 [C][stride] (device, 16-byte aligned, stride a multiple of 16), in_len[c] <= stride bytes of channel c;
+           out = uint8 [C][cap] slabs of 32-bit big-endian words (cap a multiple of 16, >= dega_hip_lzmh_worst_case_bytes(n)
+           never overflows), out_bits[c] = exact bit length, err[c] = 0 | ERROR_MEMORY (slab too small) | ERROR_INVALID_VALUE.
+   decode: the inverse: in/cap/in_bits as produced by encode (cap a multiple of 4), out = uint8 [C][stride] (stride a
+           multiple of 8), out_len[c] = decoded bytes; ERROR_MEMORY when a channel does not fit its row.
+   render: the synthetic LZMH workload of SURVEY.md 8(d): int32 channels [T][ld] (centi-units) as ASCII "%d.%02d\n" lines. */
+size_t dega_hip_lzmh_worst_case_bytes(size_t n);
+int dega_hip_lzmh_encode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out, size_t cap,
+                             uint64_t *out_bits, int32_t *err, void *stream);
+int dega_hip_lzmh_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride,
+                             uint64_t *out_len, int32_t *err, void *stream);
+int dega_hip_lzmh_render_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, uint8_t *out, size_t stride,
+                             uint64_t *out_len, int32_t *err, void *stream);
+int dega_hip_lzmh_encode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out, size_t cap,
+                              uint64_t *out_bits, int32_t *err);
+int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride,
+                              uint64_t *out_len, int32_t *err);
+
 /* ---- host-pointer convenience (H2D, kernels, D2H; synchronous) ---------------------------------------------------- */
 int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                          uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
@@ -111,7 +133,7 @@ int dega_hip_decode_f32_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t ca
                                  float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err);
 
 /* ---- measurement hook ---------------------------------------------------------------------------------------------- */
-/* Average duration in milliseconds of the encode (which=0) / decode (which=1) kernel launches enqueued since the last
+/* Average duration in milliseconds of the DEGA encode (which=0) / DEGA decode (1) / LZMH encode (2) / LZMH decode (3) kernel launches enqueued since the last
    reset, measured with hipEvents on the stream each launch used (enabled with dega_hip_profile(ctx, 1)); returns the
    number of launches measured.  Used by bench.py for the roofline figure. */
 int dega_hip_profile(dega_hip_ctx *ctx, int enable);

@@ -5,6 +5,7 @@
 #include "hipsim.hpp"
 
 #include "../../data-compressor_amd/csrc/dega_kernels.hpp"
+#include "../../data-compressor_amd/csrc/lzmh_kernels.hpp"
 
 #include <vector>
 
@@ -171,4 +172,25 @@ extern "C" __attribute__((visibility("default"))) int sim_fast_vs_slow(uint64_t 
   *fast_taken = 0;
   *redo_taken = 0;
   return adaptive ? fast_vs_slow<true>(seed, rounds, fast_taken, redo_taken) : fast_vs_slow<false>(seed, rounds, fast_taken, redo_taken);
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_lzmh_encode(const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
+{
+  LzmhEncodeArgs a{in, stride, in_len, C, out, cap, bits, err};
+  sim::launch(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
+  return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_lzmh_render(const int32_t *x, size_t C, size_t T, size_t ld, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
+{
+  RenderArgs a{x, C, T, ld, out, stride, out_len, err};
+  sim::launch(lzmh_render_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), a);
+  return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
+{
+  LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
+  sim::launch(lzmh_decode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
+  return 0;
 }

@@ -204,3 +204,29 @@ def test_cli_batch_container_round_trip(lib, tmp_path):
         ret, b, n = orc.encode_i32(x[:, c].astype(np.int32), 1)
         assert ret == 0 and n == lens[c] and blob[off: off + len(b)] == b
         off += (lens[c] + 7) // 8
+
+
+@pytest.mark.gpu
+def test_cli_glzmh_on_reference_test_file(lib, tmp_path):
+    """`encode glzmh` of the reference's test file is the file `encode lzmh` writes (270 896 bytes, sha256 c493269c...,
+    SURVEY.md Appendix B) and `decode glzmh` restores the text."""
+    import hashlib
+    import json
+    with open(os.path.join(GOLDEN, "lzmh.json")) as f:
+        meta = json.load(f)["testfile"]
+    with gzip.open(os.path.join(GOLDEN, "input.txt.gz"), "rb") as f:
+        raw = f.read()
+    src = tmp_path / "input.txt"
+    src.write_bytes(raw)
+    out = tmp_path / "out.lzmh"
+    p = run_cli([str(src), str(out), "encode", "glzmh"])
+    assert p.returncode == 0, p.stderr
+    data = out.read_bytes()
+    assert len(data) == meta["file_bytes"] and hashlib.sha256(data).hexdigest() == meta["sha256"]
+    assert "Wrote %d bytes and %d bits" % (meta["wrote_bytes"], meta["wrote_bits"]) in p.stdout
+    back = tmp_path / "back.txt"
+    p = run_cli([str(out), str(back), "decode", "glzmh"])  # from the zero-padded file, as DCCLI would
+    assert p.returncode == 0, p.stderr
+    assert back.read_bytes() == raw
+    p = run_cli([str(src), str(back), "encode", "glzmh", "#", "decode", "glzmh"])  # chained: exact bit length hand-off
+    assert p.returncode == 0 and back.read_bytes() == raw
