@@ -27,6 +27,33 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
+def _cpu_encode_columns(cols):
+    """Pool worker (forked before the GPU is touched, never touches it): encodes its channels with the CPU chain."""
+    from oracle import orc
+    use_ref = orc.have_ref()
+    n = 0
+    for col in cols:
+        if use_ref:
+            orc.ref_encode_i32(col, 1)
+        else:
+            orc.encode_i32(col, 1)
+        n += col.size
+    return n
+
+
+def cpu_all_cores(pool, ncores, x_sample):
+    """The same CPU chain, process-parallel over all host cores (CPU baseline (ii)); channels strided."""
+    import numpy as np
+    from oracle import orc
+    T, n = x_sample.shape
+    chunks = [[np.ascontiguousarray(x_sample[:, c]) for c in range(k, n, ncores)] for k in range(ncores)]
+    t0 = time.perf_counter()
+    done = sum(pool.map(_cpu_encode_columns, chunks))
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt / 1e6, 3), "unit": "Msamples/s", "cores": ncores, "kind": "reference" if orc.have_ref() else "port",
+            "sample": "%d channels x %d samples over %d processes, %.1f s (includes handing the samples to the workers)" % (n, T, ncores, dt)}
+
+
 def cpu_baseline(x_sample, gpu_out, gpu_bits, adaptive=1):
     """Time the CPU chain on the sample channels (single thread) and check the GPU streams against it."""
     import numpy as np
@@ -63,7 +90,14 @@ def main():
     ap.add_argument("--cap-bytes-per-sample", type=float, default=4.0, help="slab bytes per sample per channel")
     ap.add_argument("--cpu-channels", type=int, default=256, help="channels of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-round-trip", action="store_true", help="skip the decode + compare after the timed region")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the process-parallel CPU baseline")
+    ap.add_argument("--end-to-end-channels", type=int, default=8192,
+                    help="channels of the host-pointer (PCIe-inclusive) measurement after the timed region (0 = skip)")
+    ap.add_argument("--workload", choices=("dega", "lzmh"), default="dega",
+                    help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH")
     args = ap.parse_args()
+    if args.workload == "lzmh":
+        return main_lzmh(args)
 
     import numpy as np
     import torch
@@ -73,6 +107,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pool, ncores = None, 0
+    if world == 1 and args.cpu_channels > 0 and not args.no_all_cores:
+        # worker processes for the all-core CPU baseline are forked here, before anything touches the GPU
+        import multiprocessing as mp
+        ncores = len(os.sched_getaffinity(0))
+        pool = mp.get_context("fork").Pool(ncores)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -175,7 +215,156 @@ def main():
             res["round_trip"] = round_trip
         if world == 1 and args.cpu_channels > 0:
             n = min(args.cpu_channels, C_)
-            res["cpu_baseline"] = cpu_baseline(x[:, :n].cpu().numpy(), out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
+            xs = x[:, :n].cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(xs, out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
+            res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+            if pool is not None:
+                res["cpu_all_cores"] = cpu_all_cores(pool, ncores, xs)
+        if world == 1 and args.end_to_end_channels > 0:
+            # the host-pointer entry point of the C ABI: allocation + H2D + kernel + D2H, never the headline value
+            n = min(args.end_to_end_channels, C_)
+            xh = np.ascontiguousarray(x[:, :n].cpu().numpy())
+            t0 = time.perf_counter()
+            ho, hb, he = ctx.encode_host(xh, adaptive=1, cap=cap)
+            dt = time.perf_counter() - t0
+            res["end_to_end"] = {"value": round(n * T / dt / 1e6, 2), "unit": "Msamples/s", "channels": n, "seconds": round(dt, 3),
+                                 "what": "dega_hip_encode_host: device alloc + H2D of pageable memory + kernel + D2H of the slabs",
+                                 "streams_equal_device_resident": bool((hb.astype(np.int64) == bits[:n].cpu().numpy()).all())}
+        print(json.dumps(res), flush=True)
+    if pool is not None:
+        pool.close()
+        pool.join()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def lzmh_cpu_baseline(texts, gpu_out, gpu_bits):
+    """The reference's `encode lzmh` (oracle/_ref; else our C port) on the sample channels, single thread."""
+    from oracle import orc  # the checker / baseline, never the measured product path
+
+    use_ref = orc.have_ref()
+    t0 = time.perf_counter()
+    mismatches = 0
+    nbytes = 0
+    for c, s in enumerate(texts):
+        if use_ref:
+            ret, b, nb, _ = orc.ref_run_chain(s, 8 * len(s), ["encode lzmh"])
+        else:
+            ret, b, nb = orc.stage("lzmh", True, s, 8 * len(s))
+        nbytes += len(s)
+        if ret != 0 or nb != int(gpu_bits[c]) or gpu_out[c, : (nb + 7) // 8].tobytes() != b[: (nb + 7) // 8]:
+            mismatches += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(nbytes / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+            "sample": "%d channels (%d bytes of ASCII) of the same workload, encode lzmh per channel, %.1f s" % (len(texts), nbytes, dt),
+            "gpu_streams_bit_exact": mismatches == 0}
+
+
+def main_lzmh(args):
+    """BASELINE configs[3]: LZMH encode of the cfg2 channels rendered as ASCII "%d.%02d\\n" lines, one GPU
+    lane per channel.  Same contract as the DEGA line; the unit is bytes of text."""
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dca = load_package()
+    ctx = dca.Context(local_rank)
+    C_, T = args.channels, args.samples
+    x = torch.empty((T, C_), dtype=torch.int32, device=dev)
+    ctx.synth(C_, T, seed=1234, c0=rank * C_, S=args.step_size, out=x)
+    stride = 16 * ((T * 8 + 64 + 15) // 16)
+    text, lens, rerr = ctx.lzmh_render(x, stride)
+    del x
+    assert int((rerr != 0).sum().item()) == 0, "a channel's text does not fit its row"
+    cap = 16 * ((stride * 3 // 4 + 63) // 16)
+    out = torch.zeros((C_, cap), dtype=torch.uint8, device=dev)
+    bits = torch.zeros(C_, dtype=torch.int64, device=dev)
+    err = torch.zeros(C_, dtype=torch.int32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.lzmh_encode(text, lens, cap=cap, out=out, bits=bits, err=err)
+    barrier()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.lzmh_encode(text, lens, cap=cap, out=out, bits=bits, err=err)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    n_launch, kernel_ms = ctx.profile_read(2)
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    elapsed = float(t_all.item())
+    in_bytes = int(lens.sum().item())
+    tot = torch.tensor([in_bytes], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_bytes = int(tot.item())
+
+    round_trip = None
+    if not args.no_round_trip:
+        back = torch.zeros((C_, stride), dtype=torch.uint8, device=dev)
+        ctx.profile(True)
+        back, blens, derr = ctx.lzmh_decode(out, bits, stride, out=back)
+        torch.cuda.synchronize()
+        ctx.profile(False)
+        _, dec_ms = ctx.profile_read(3)
+        ok = bool((blens == lens).all().item()) and int((derr != 0).sum().item()) == 0
+        for c0 in range(0, C_, 8192):  # compare in slices: the mask of a whole 45 GB batch would not fit beside it
+            sl = slice(c0, min(C_, c0 + 8192))
+            idx = torch.arange(stride, device=dev)[None, :] < lens[sl, None]
+            ok = ok and bool(((back[sl] == text[sl]) | ~idx).all().item())
+        flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        round_trip = {"bit_exact": bool(flags.item()), "decode_kernel_ms": round(dec_ms, 3),
+                      "decode_mb_per_s_per_gpu": round(in_bytes / (dec_ms * 1e-3) / 1e6, 1) if dec_ms > 0 else None}
+        del back
+
+    out_bytes = int(((bits + 7) // 8).sum().item())
+    algo_bytes = float(in_bytes + out_bytes)  # every text byte read once + the stream bytes written
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    if rank == 0:
+        res = {
+            "metric": "MB/s LZMH encode (ASCII lines)", "value": round(total_bytes * args.steps / elapsed / 1e6, 2), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "LZMH encode, %d channels x %d samples per GPU rendered as ASCII '%%d.%%02d\\n' lines (%.2f GB), resident in HBM" % (C_, T, in_bytes / 1e9),
+                "channels_per_gpu": C_, "samples_per_channel": T, "random_walk_step": args.step_size, "seed": 1234,
+                "text_bytes_per_gpu": in_bytes, "row_bytes_per_channel": stride, "slab_bytes_per_channel": cap,
+                "bits_per_byte_out": round(out_bytes * 8.0 / max(1, in_bytes), 4), "channels_in_error": int((err != 0).sum().item()),
+                "partitioning": "channel ranges per GPU, no collective",
+            },
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel": "lzmh_encode_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch,
+                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+        }
+        if round_trip is not None:
+            res["round_trip"] = round_trip
+        if world == 1 and args.cpu_channels > 0:
+            # a bounded sample: the reference codes ~5 MB/s, so ~16 channels of 600 kB are ~2 s each
+            n = min(max(1, args.cpu_channels // 16), C_)
+            lc = lens[:n].cpu().numpy()
+            tc = text[:n].cpu().numpy()
+            texts = [tc[c, : int(lc[c])].tobytes() for c in range(n)]
+            res["cpu_baseline"] = lzmh_cpu_baseline(texts, out[:n].cpu().numpy(), bits[:n].cpu().numpy())
             res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -136,7 +136,7 @@ class Context:
         return _P(torch.cuda.current_stream().cuda_stream)
 
     # ---- device-resident API (torch tensors) ---------------------------------------------------------------------
-    def encode(self, x_tc, adaptive=1, cap=None, out=None, bits=None, err=None):
+    def encode(self, x_tc, adaptive=1, cap=None, out=None, bits=None, err=None, valuesize=32):
         """x_tc: int32 CUDA tensor [T, ld>=C].  Returns (out uint8 [C, cap], bits int64 [C] (bit lengths), err int32 [C])."""
         import torch
         T, ld = x_tc.shape
@@ -150,12 +150,12 @@ class Context:
             bits = torch.zeros(Cn, dtype=torch.int64, device=x_tc.device)
         if err is None:
             err = torch.zeros(Cn, dtype=torch.int32, device=x_tc.device)
-        ret = library().dega_hip_encode_dev(self._h, x_tc.data_ptr(), Cn, T, ld, int(adaptive), 32, out.data_ptr(), cap,
+        ret = library().dega_hip_encode_dev(self._h, x_tc.data_ptr(), Cn, T, ld, int(adaptive), int(valuesize), out.data_ptr(), cap,
                                             bits.data_ptr(), err.data_ptr(), self._stream())
         self._check(ret, "dega_hip_encode_dev")
         return out, bits, err
 
-    def decode(self, streams, bits, T, adaptive=1, x_tc=None, err=None):
+    def decode(self, streams, bits, T, adaptive=1, x_tc=None, err=None, valuesize=32):
         import torch
         Cn, cap = streams.shape
         assert streams.dtype == torch.uint8 and streams.is_cuda and streams.is_contiguous() and bits.dtype == torch.int64
@@ -163,26 +163,26 @@ class Context:
             x_tc = torch.zeros((T, Cn), dtype=torch.int32, device=streams.device)
         if err is None:
             err = torch.zeros(Cn, dtype=torch.int32, device=streams.device)
-        ret = library().dega_hip_decode_dev(self._h, streams.data_ptr(), cap, bits.data_ptr(), Cn, T, x_tc.shape[1], int(adaptive), 32,
+        ret = library().dega_hip_decode_dev(self._h, streams.data_ptr(), cap, bits.data_ptr(), Cn, T, x_tc.shape[1], int(adaptive), int(valuesize),
                                             x_tc.data_ptr(), err.data_ptr(), self._stream())
         self._check(ret, "dega_hip_decode_dev")
         return x_tc, err
 
-    def normalize(self, v_tc, factor=100.0):
+    def normalize(self, v_tc, factor=100.0, valuesize=32):
         import torch
         T, Cn = v_tc.shape
         assert v_tc.dtype == torch.float32 and v_tc.is_cuda and v_tc.is_contiguous()
         x = torch.empty((T, Cn), dtype=torch.int32, device=v_tc.device)
         err = torch.zeros(Cn, dtype=torch.int32, device=v_tc.device)
-        ret = library().dega_hip_normalize_dev(self._h, v_tc.data_ptr(), Cn, T, Cn, float(factor), 32, x.data_ptr(), err.data_ptr(), self._stream())
+        ret = library().dega_hip_normalize_dev(self._h, v_tc.data_ptr(), Cn, T, Cn, float(factor), int(valuesize), x.data_ptr(), err.data_ptr(), self._stream())
         self._check(ret, "dega_hip_normalize_dev")
         return x, err
 
-    def denormalize(self, x_tc, factor=100.0):
+    def denormalize(self, x_tc, factor=100.0, valuesize=32):
         import torch
         T, Cn = x_tc.shape
         v = torch.empty((T, Cn), dtype=torch.float32, device=x_tc.device)
-        ret = library().dega_hip_denormalize_dev(self._h, x_tc.data_ptr(), Cn, T, Cn, float(factor), 32, v.data_ptr(), self._stream())
+        ret = library().dega_hip_denormalize_dev(self._h, x_tc.data_ptr(), Cn, T, Cn, float(factor), int(valuesize), v.data_ptr(), self._stream())
         self._check(ret, "dega_hip_denormalize_dev")
         return v
 
@@ -297,7 +297,7 @@ class Context:
         return n, avg.value
 
     # ---- host-pointer API (numpy) ---------------------------------------------------------------------------------
-    def encode_host(self, x_tc, adaptive=1, cap=None):
+    def encode_host(self, x_tc, adaptive=1, cap=None, valuesize=32):
         import numpy as np
         x_tc = np.ascontiguousarray(x_tc, dtype=np.int32)
         T, Cn = x_tc.shape
@@ -306,22 +306,22 @@ class Context:
         out = np.zeros((Cn, cap), dtype=np.uint8)
         bits = np.zeros(Cn, dtype=np.uint64)
         err = np.zeros(Cn, dtype=np.int32)
-        ret = library().dega_hip_encode_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), 32, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+        ret = library().dega_hip_encode_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), int(valuesize), out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_encode_host")
         return out, bits, err
 
-    def decode_host(self, streams, bits, T, adaptive=1):
+    def decode_host(self, streams, bits, T, adaptive=1, valuesize=32):
         import numpy as np
         streams = np.ascontiguousarray(streams, dtype=np.uint8)
         bits = np.ascontiguousarray(bits, dtype=np.uint64)
         Cn, cap = streams.shape
         x = np.zeros((T, Cn), dtype=np.int32)
         err = np.zeros(Cn, dtype=np.int32)
-        ret = library().dega_hip_decode_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, int(adaptive), 32, x.ctypes.data, err.ctypes.data)
+        ret = library().dega_hip_decode_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, int(adaptive), int(valuesize), x.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_decode_host")
         return x, err
 
-    def decode_var_host(self, streams, bits, max_T, adaptive=1):
+    def decode_var_host(self, streams, bits, max_T, adaptive=1, valuesize=32):
         """Decode streams of unknown length: returns (x [max_T, C], counts uint64 [C], err)."""
         import numpy as np
         streams = np.ascontiguousarray(streams, dtype=np.uint8)
@@ -330,12 +330,12 @@ class Context:
         x = np.zeros((max_T, Cn), dtype=np.int32)
         counts = np.zeros(Cn, dtype=np.uint64)
         err = np.zeros(Cn, dtype=np.int32)
-        ret = library().dega_hip_decode_var_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, max_T, Cn, int(adaptive), 32,
+        ret = library().dega_hip_decode_var_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, max_T, Cn, int(adaptive), int(valuesize),
                                                  x.ctypes.data, counts.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_decode_var_host")
         return x, counts, err
 
-    def encode_f32_host(self, v_tc, factor=100.0, adaptive=1, cap=None):
+    def encode_f32_host(self, v_tc, factor=100.0, adaptive=1, cap=None, valuesize=32):
         import numpy as np
         v_tc = np.ascontiguousarray(v_tc, dtype=np.float32)
         T, Cn = v_tc.shape
@@ -344,18 +344,18 @@ class Context:
         out = np.zeros((Cn, cap), dtype=np.uint8)
         bits = np.zeros(Cn, dtype=np.uint64)
         err = np.zeros(Cn, dtype=np.int32)
-        ret = library().dega_hip_encode_f32_host(self._h, v_tc.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), 32, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+        ret = library().dega_hip_encode_f32_host(self._h, v_tc.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), int(valuesize), out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_encode_f32_host")
         return out, bits, err
 
-    def decode_f32_host(self, streams, bits, T, factor=100.0, adaptive=1):
+    def decode_f32_host(self, streams, bits, T, factor=100.0, adaptive=1, valuesize=32):
         import numpy as np
         streams = np.ascontiguousarray(streams, dtype=np.uint8)
         bits = np.ascontiguousarray(bits, dtype=np.uint64)
         Cn, cap = streams.shape
         v = np.zeros((T, Cn), dtype=np.float32)
         err = np.zeros(Cn, dtype=np.int32)
-        ret = library().dega_hip_decode_f32_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), 32, v.ctypes.data, err.ctypes.data)
+        ret = library().dega_hip_decode_f32_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, T, Cn, float(factor), int(adaptive), int(valuesize), v.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_decode_f32_host")
         return v, err
 

@@ -205,8 +205,8 @@ static int check_shape(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t 
   (void)T;
   if (ctx == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
-  if (valuesize != 32)
-    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "valuesize must be 32 for the [T][C] int32 layout", hipSuccess);
+  if (valuesize < 1 || valuesize > 32)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "valuesize must be 1..32 for the [T][C] int32 layout", hipSuccess);
   if (ld < C)
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "ld < C", hipSuccess);
   if (cap % 4 != 0 || cap > ((size_t)1 << 29))
@@ -235,11 +235,19 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   a.out_bits = out_bits;
   a.err = err;
   a.div_magic = ctx->div_magic;
+  a.valuesize = (uint32_t)valuesize;
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 0, s);
-    if (adaptive)
+    if (valuesize < 32) // the narrow variants mask the samples and range check against the value size
+    {
+      if (adaptive)
+        hipLaunchKernelGGL((dega_encode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL((dega_encode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+    }
+    else if (adaptive)
       hipLaunchKernelGGL(dega_encode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
     else
       hipLaunchKernelGGL(dega_encode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
@@ -268,11 +276,19 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
   a.err = err;
   a.div_magic = ctx->div_magic;
   a.out_count = out_count;
+  a.valuesize = (uint32_t)valuesize;
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 1, s);
-    if (adaptive)
+    if (valuesize < 32)
+    {
+      if (adaptive)
+        hipLaunchKernelGGL((dega_decode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL((dega_decode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+    }
+    else if (adaptive)
       hipLaunchKernelGGL(dega_decode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
     else
       hipLaunchKernelGGL(dega_decode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
@@ -318,7 +334,9 @@ extern "C" int dega_hip_normalize_dev(dega_hip_ctx *ctx, const float *v_tc, size
   HIP_TRY(ctx, hipMemsetAsync(err, 0, C * sizeof(int32_t), s), DEGA_ERROR_LIBRARY_CALL);
   if (T == 0)
     return DEGA_OK;
-  NormalizeArgs a{v_tc, x_tc, C, T, ld, factor, err};
+  // the bounds of normalize.c:21, rounded to float by the host compiler exactly as the reference's are
+  const float lo = -(float)((uint64_t)1 << (valuesize - 1)), hi = (float)(((uint64_t)1 << (valuesize - 1)) - 1);
+  NormalizeArgs a{v_tc, x_tc, C, T, ld, factor, err, lo, hi, valuesize >= 32 ? 0xFFFFFFFFu : (1u << valuesize) - 1u};
   hipLaunchKernelGGL(dega_normalize_kernel, rowsplit_grid(C, T), dim3(BLOCK), 0, s, a);
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
@@ -333,7 +351,7 @@ extern "C" int dega_hip_denormalize_dev(dega_hip_ctx *ctx, const int32_t *x_tc, 
   if (C == 0 || T == 0)
     return DEGA_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DenormalizeArgs a{x_tc, v_tc, C, T, ld, factor};
+  DenormalizeArgs a{x_tc, v_tc, C, T, ld, factor, (uint32_t)(32 - valuesize)};
   hipLaunchKernelGGL(dega_denormalize_kernel, rowsplit_grid(C, T), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;

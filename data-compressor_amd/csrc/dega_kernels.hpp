@@ -113,6 +113,7 @@ struct EncodeArgs
   uint64_t *out_bits;
   int32_t *err;
   const uint32_t *div_magic; // DIV_TABLE_SIZE division magics (dega_lane.hpp), global memory
+  uint32_t valuesize;        // 1..32: samples are the low valuesize bits of x, unsigned (diff.c:15)
 };
 
 template <bool ADAPTIVE>
@@ -128,9 +129,11 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
   __syncthreads();
 }
 
-template <bool ADAPTIVE>
+template <bool ADAPTIVE, bool NARROW = false>
 __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 {
+  // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
+  const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
   // access with a vmcnt(0) wait):  division magics (64 KiB) | seg-bit rings | coded-word rings | input rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
       uint32_t xr[ENC_ROWS];
 #pragma unroll
       for (uint32_t i = 0; i < ENC_ROWS; i++)
-        xr[i] = rows_col[i * 64u];
+        xr[i] = NARROW ? rows_col[i * 64u] & vmask : rows_col[i * 64u];
 #pragma unroll
       for (uint32_t i = 0; i < ENC_ROWS; i++)
         DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
       for (uint32_t i = 0; i < ENC_ROWS; i++)
       {
         bool ok, wide;
-        w[i] = diff_seg_short(xr[i], last_try, ok, wide);
+        w[i] = diff_seg_short<NARROW>(xr[i], last_try, ok, wide, vhalf);
         all_ok = all_ok && ok;
         any_wide = any_wide || wide;
       }
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
         {
           if (i < left)
           {
-            const SegWord sw = diff_seg(xr[i], last);
+            const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
             if (!sw.ok && lane_err == OK)
               lane_err = ERR_INVALID_VALUE;
             q.put_codeword<ENC_RING>(sw, ring_col);
@@ -393,9 +396,10 @@ struct DecodeArgs
   int32_t *err;
   const uint32_t *div_magic;
   uint64_t *out_count; // NULL: every channel must hold exactly T samples.  Else: up to T samples, count reported here
+  uint32_t valuesize;  // 1..32: samples come out as the low valuesize bits, zero extended (diff.c:34)
 };
 
-template <bool ADAPTIVE>
+template <bool ADAPTIVE, bool NARROW = false>
 __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
@@ -425,7 +429,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
   BacDecoder<ADAPTIVE> dec;
   dec.init();
   SegParser sp;
-  sp.init();
+  sp.init(NARROW ? a.valuesize : 32u);
   uint32_t seg_bits = 0; // seg bits decoded so far
 
   uint32_t in_loaded = 0;    // stream words staged so far (a multiple of 4 until the end)
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
         {
           uint32_t sample;
           const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
-          const bool took = sp.take_short(allowed, sample);
+          const bool took = sp.take_short<NARROW>(allowed, sample);
           sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
           t_lane += took ? 1u : 0u;
           more = took;
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
           else
           {
             uint32_t sample = 0;
-            const int32_t r = sp.next(bac_done, sample);
+            const int32_t r = sp.next<NARROW>(bac_done, sample);
             if (r == 1)
             {
               if (t_lane >= a.T)
@@ -665,7 +669,9 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
 // normalize / denormalize (DCLib/src/normalize.c), elementwise, HBM bound.  Float parity rules: the
 // multiply and the +-0.5 are two separately rounded operations (no FMA), truncating convert, IEEE division.
 // ---------------------------------------------------------------------------------------------------------------------
-DG_DEV bool normalize_value(float v, float factor, int32_t &out)
+// lo = -(float)2^(valuesize-1), hi = (float)(2^(valuesize-1) - 1) as the host's C compiler rounds them (normalize.c:21;
+// hi rounds up to 2^(valuesize-1) from valuesize 26 on), mask = the low valuesize bits written (normalize.c:24)
+DG_DEV bool normalize_value(float v, float factor, int32_t &out, float lo = -2147483648.0f, float hi = 2147483648.0f, uint32_t mask = 0xFFFFFFFFu)
 {
 #if defined(DEGA_SIM)
   volatile float prod;
@@ -685,8 +691,8 @@ DG_DEV bool normalize_value(float v, float factor, int32_t &out)
   else if (v < 0.0f)
     v = __fsub_rn(__fmul_rn(v, factor), 0.5f); // :19-20
 #endif
-  const bool ok = !(v < -2147483648.0f || v > 2147483648.0f); // :21 -- (float)(2^31-1) is 2^31, so exactly 2^31 passes
-  out = v >= 2147483648.0f ? (int32_t)0x80000000u : (int32_t)v; // :23 (int64) truncation, low 32 bits
+  const bool ok = !(v < lo || v > hi); // :21 -- for valuesize 32 (float)(2^31-1) is 2^31, so exactly 2^31 passes
+  out = (int32_t)((v >= 2147483648.0f ? 0x80000000u : (uint32_t)(int32_t)v) & mask); // :23-24 (int64) truncation, low valuesize bits
   return ok;
 }
 
@@ -697,6 +703,8 @@ struct NormalizeArgs
   size_t C, T, ld;
   float factor;
   int32_t *err; // [C], pre-zeroed
+  float lo, hi; // range of normalize.c:21 for the value size
+  uint32_t mask;
 };
 
 __global__ void __launch_bounds__(256) dega_normalize_kernel(const NormalizeArgs a)
@@ -711,7 +719,7 @@ __global__ void __launch_bounds__(256) dega_normalize_kernel(const NormalizeArgs
   for (size_t t = t0; t < t1; t++)
   {
     int32_t n;
-    bad |= !normalize_value(a.v[t * a.ld + c], a.factor, n);
+    bad |= !normalize_value(a.v[t * a.ld + c], a.factor, n, a.lo, a.hi, a.mask);
     a.x[t * a.ld + c] = n;
   }
   if (bad)
@@ -724,6 +732,7 @@ struct DenormalizeArgs
   float *v;
   size_t C, T, ld;
   float factor;
+  uint32_t vshift; // 32 - valuesize: the value is the low valuesize bits, sign extended (normalize.c:36-37)
 };
 
 __global__ void __launch_bounds__(256) dega_denormalize_kernel(const DenormalizeArgs a)
@@ -736,10 +745,11 @@ __global__ void __launch_bounds__(256) dega_denormalize_kernel(const Denormalize
   const size_t t1 = t0 + rows_per_block < a.T ? t0 + rows_per_block : a.T;
   for (size_t t = t0; t < t1; t++)
   {
+    const int32_t n = (int32_t)((uint32_t)a.x[t * a.ld + c] << a.vshift) >> a.vshift;
 #if defined(DEGA_SIM)
-    a.v[t * a.ld + c] = (float)a.x[t * a.ld + c] / a.factor;
+    a.v[t * a.ld + c] = (float)n / a.factor;
 #else
-    a.v[t * a.ld + c] = __fdiv_rn((float)a.x[t * a.ld + c], a.factor); // normalize.c:38, true division
+    a.v[t * a.ld + c] = __fdiv_rn((float)n, a.factor); // normalize.c:38, true division
 #endif
   }
 }

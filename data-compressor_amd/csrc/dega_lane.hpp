@@ -535,11 +535,17 @@ struct SegWord
   bool ok;       // false: the difference does not fit 32 bits -> ERROR_INVALID_VALUE (diff.c:17-18)
 };
 
-DG_DEV SegWord diff_seg(uint32_t u, uint32_t &last)
+// valuesize < 32 (NARROW): u and last are below 2^valuesize, the difference is exact in 32 bits and must lie in
+// [-half, half - 1] with half = 2^(valuesize-1) (diff.c:17-18); the codeword is the same function of the difference.
+template <bool NARROW = false>
+DG_DEV SegWord diff_seg(uint32_t u, uint32_t &last, uint32_t half = 0x80000000u)
 {
   SegWord r;
   const uint32_t d = u - last;                       // low 32 bits of (int64)u - (int64)last; u is zero extended (diff.c:15)
-  r.ok = (u >= last) == ((int32_t)d >= 0);           // fits int32 <=> sign of the wrapped difference is the true sign
+  if (NARROW)
+    r.ok = d + half < 2u * half;
+  else
+    r.ok = (u >= last) == ((int32_t)d >= 0);         // fits int32 <=> sign of the wrapped difference is the true sign
   last = u;
   const int32_t v = (int32_t)d;
   if (v > 0)
@@ -559,10 +565,14 @@ DG_DEV SegWord diff_seg(uint32_t u, uint32_t &last)
 // diff + seg for the common case, branch free: returns w (the codeword's value; its length is 2*floor(log2 w) + 1 bits).
 // w = zigzag(-v) + 1 with v = x - last:  v > 0 -> 2v,  v <= 0 -> 2|v| + 1  (seg.c:25-28 + the "+1" of seg.c:13).
 // Only valid when the result fits 16 bits (codeword <= 31 bits); `wide` says when it does not (or v = INT32_MIN).
-DG_DEV uint32_t diff_seg_short(uint32_t u, uint32_t &last, bool &ok, bool &wide)
+template <bool NARROW = false>
+DG_DEV uint32_t diff_seg_short(uint32_t u, uint32_t &last, bool &ok, bool &wide, uint32_t half = 0x80000000u)
 {
   const uint32_t nv = last - u;                                    // -v, low 32 bits
-  ok = (u >= last) == ((int32_t)nv <= 0);                          // diff.c:17-18: the true difference fits int32
+  if (NARROW)
+    ok = half - nv < 2u * half;                                    // -half <= v <= half - 1
+  else
+    ok = (u >= last) == ((int32_t)nv <= 0);                        // diff.c:17-18: the true difference fits int32
   last = u;
   const uint32_t w = ((nv << 1) ^ (uint32_t)((int32_t)nv >> 31)) + 1u;
   wide = (w >> 16) != 0u || nv == 0x80000000u;
@@ -903,14 +913,21 @@ struct SegParser
   uint32_t zeros;  // zero-prefix bits of the current codeword consumed so far
   uint32_t need;   // 0: scanning a prefix; else: prefix done, need = its length + 1 bits are wanted next
   uint32_t last;   // diff.c:27
+  // valuesize < 32 (the NARROW variants below): the zero prefix is capped at valuesize + 1 bits (seg.c:55-56,74), decode
+  // diff reads the decoded value back as valuesize bits, sign extended (diff.c:31-32), and writes the low valuesize
+  // bits of the running sum (diff.c:34)
+  uint32_t pmax, vshift, vmask;
 
-  DG_DEV void init()
+  DG_DEV void init(uint32_t valuesize = 32)
   {
     win = 0;
     cnt = 0;
     zeros = 0;
     need = 0;
     last = 0;
+    pmax = valuesize < 15u ? valuesize : 15u;
+    vshift = 32u - valuesize;
+    vmask = valuesize >= 32u ? 0xFFFFFFFFu : (1u << valuesize) - 1u;
   }
 
   DG_DEV bool has_room() const // for 32 more bits
@@ -933,29 +950,35 @@ struct SegParser
     cnt -= n;
   }
 
+  template <bool NARROW = false>
   DG_DEV void emit(uint64_t w, uint32_t &sample) // w = code_number + 1
   {
     const uint32_t mag = (uint32_t)(w >> 1);       // (code_number + 1) / 2, seg.c:76
-    const uint32_t d = (w & 1u) ? 0u - mag : mag;  // odd w = even code number = negative (seg.c:77-78)
+    uint32_t d = (w & 1u) ? 0u - mag : mag;        // odd w = even code number = negative (seg.c:77-78)
+    if (NARROW)
+      d = (uint32_t)((int32_t)(d << vshift) >> vshift);
     last += d;                                     // diff.c:32-35
-    sample = last;
+    sample = NARROW ? last & vmask : last;
   }
 
   // Branch-free attempt at the common case: a whole codeword of <= 31 bits on top of the window, parser between
   // codewords, `allowed` (room in the sample ring, count below T, lane not finished).  Returns true and the sample if it
   // took one; otherwise changes nothing.
+  template <bool NARROW = false>
   DG_DEV bool take_short(bool allowed, uint32_t &sample)
   {
     const uint32_t top = (uint32_t)(win >> 32);
     const uint32_t p = clz32(top | 0x8000u); // 16 = no short codeword here
     const uint32_t n = 2u * p + 1u;
-    const bool ok = allowed && (need | zeros) == 0u && p <= 15u && n <= cnt;
+    const bool ok = allowed && (need | zeros) == 0u && p <= (NARROW ? pmax : 15u) && n <= cnt;
     const uint32_t w = top >> ((32u - n) & 31u);
     const uint32_t mag = w >> 1;
-    const uint32_t d = (w & 1u) ? 0u - mag : mag;
+    uint32_t d = (w & 1u) ? 0u - mag : mag;
+    if (NARROW)
+      d = (uint32_t)((int32_t)(d << vshift) >> vshift);
     const uint32_t m = ok ? n : 0u;
     last += ok ? d : 0u;
-    sample = last;
+    sample = NARROW ? last & vmask : last;
     win <<= m;
     cnt -= m;
     return ok;
@@ -963,6 +986,7 @@ struct SegParser
 
   // Tries to parse one codeword.  Returns 1 and the sample if a complete codeword was available, 0 if more bits are
   // needed (and `final` is false), 2 at a clean end of stream, or a negative error code.
+  template <bool NARROW = false>
   DG_DEV int32_t next(bool final, uint32_t &sample)
   {
     if (need == 0 && zeros == 0)
@@ -971,9 +995,9 @@ struct SegParser
       const uint32_t top = (uint32_t)(win >> 32);
       const uint32_t p = top ? clz32(top) : 32u;
       const uint32_t n = 2u * p + 1u;
-      if (p <= 15u && n <= cnt)
+      if (p <= (NARROW ? pmax : 15u) && n <= cnt)
       {
-        emit(top >> (32u - n), sample);
+        emit<NARROW>(top >> (32u - n), sample);
         drop(n);
         return 1;
       }
@@ -990,7 +1014,7 @@ struct SegParser
       const uint32_t lz = win ? (uint32_t)__builtin_clzll(win) : 64u;
       const uint32_t z = lz < cnt ? lz : cnt;
       zeros += z;
-      if (zeros >= 33u)
+      if (zeros >= 33u - (NARROW ? vshift : 0u))
         return ERR_INVALID_FORMAT; // prefix cap: valuesize + 1 (seg.c:55-56,74)
       drop(z);
       if (cnt == 0) // ran out inside the prefix
@@ -999,8 +1023,15 @@ struct SegParser
       zeros = 0;
     }
     if (cnt < need)
-      return final ? ERR_LIBRARY_CALL : 0; // EOF inside the residual is a short read in the reference
-    emit(win >> (64u - need), sample); // (1 << prefix) | residual = code_number + 1 (seg.c:64-66)
+    {
+      // the stream ends inside this codeword.  Right after the delimiting one (cnt == 1) the reference sees EOF with a
+      // non-empty prefix and takes it for padding (seg.c:58-62, checked after the loop of :50-57); with part of the
+      // residual present its read comes up short (seg.c:64)
+      if (!final)
+        return 0;
+      return cnt == 1u ? 2 : ERR_LIBRARY_CALL;
+    }
+    emit<NARROW>(win >> (64u - need), sample); // (1 << prefix) | residual = code_number + 1 (seg.c:64-66)
     drop(need);
     need = 0;
     return 1;

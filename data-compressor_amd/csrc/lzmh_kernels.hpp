@@ -39,6 +39,7 @@ constexpr uint32_t LZ_TREE = 19;        // HUFFTREE_LENGTH, lzmh.c:70
 constexpr uint32_t LZ_BLOCK = 256;
 constexpr uint32_t LZ_WIN_DW = 112;              // window dwords per lane (448 bytes)
 constexpr uint32_t LZ_WIN_BYTES = 4 * LZ_WIN_DW;
+constexpr uint32_t LZ_POP = 5;                   // candidates of one mask register handled per pass
 constexpr uint32_t LZ_AHEAD = 48;                // look-ahead a step needs in the window: 24 bytes in registers + slack
 constexpr uint32_t LZ_SYM_DW = LZ_LIST / 4, LZ_CNT_DW = LZ_LIST / 2, LZ_STAGE_DW = 4;
 constexpr uint32_t LZ_OFF_WIN = 0, LZ_OFF_SYM = LZ_OFF_WIN + LZ_WIN_DW * LZ_BLOCK, LZ_OFF_CNT = LZ_OFF_SYM + LZ_SYM_DW * LZ_BLOCK,
@@ -172,16 +173,19 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
   uint64_t acc = 0;        // output bits, MSB first
   uint32_t nacc = 0, staged = 0, pos = 0; // bits in acc, words in stage[], words stored
   bool reload = true;
+  DG_STAMP_DECL;
 
   for (;;)
   {
     const bool active = P < n_eff && err == OK;
     if (!wave_any(active))
       break;
+    DG_STAMP(7);
 
     // ---- window: every active lane of the wave reloads [P-128 (rounded down to 16), +448) when one lane needs it ----
     if (wave_any(active && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
     {
+      DG_STAMP(0);
       if (active)
       {
         base = (int32_t)((P - LZ_HISTORY) & ~15u);
@@ -189,15 +193,13 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         for (uint32_t k = 0; k < LZ_WIN_DW / 4; k++)
         {
           const int32_t at = base + (int32_t)(16u * k);
-          uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-          if (at >= 0 && (size_t)at + 16u <= a.stride)
-          {
-            const lz_u32x4 v = *reinterpret_cast<const lz_u32x4 *>(src + at);
-            v0 = v[0];
-            v1 = v[1];
-            v2 = v[2];
-            v3 = v[3];
-          }
+          // rows before the start of the channel (at < 0) and past the end of its row read row 0 / the last 16 bytes
+          // instead and are zeroed: no branch around the load, so the 28 loads are in flight together
+          const bool inside = at >= 0 && (size_t)at + 16u <= a.stride;
+          const size_t from = inside ? (size_t)at : 0u;
+          const lz_u32x4 v = *reinterpret_cast<const lz_u32x4 *>(src + from);
+          const uint32_t keep = inside ? 0xFFFFFFFFu : 0u;
+          const uint32_t v0 = v[0] & keep, v1 = v[1] & keep, v2 = v[2] & keep, v3 = v[3] & keep;
           win[(4u * k + 0u) * LZ_BLOCK] = v0;
           win[(4u * k + 1u) * LZ_BLOCK] = v1;
           win[(4u * k + 2u) * LZ_BLOCK] = v2;
@@ -205,8 +207,10 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         }
       }
       reload = false;
+      DG_STAMP(6);
     }
 
+    DG_STAMP(0);
     // ---- bounds of this step (see the header) ----
     const uint32_t maxoff = P < LZ_HISTORY ? P : LZ_HISTORY;
     const uint32_t wabs_raw = (P > LZ_HISTORY ? P - LZ_HISTORY : 0u) + LZ_RING;
@@ -247,39 +251,92 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
       cm[4] &= ((1u << s) - 1u) & keep;
     }
 
-    // ---- phase 2: nearest candidate first; measure it unless its byte at the best length so far already differs ----
+    DG_STAMP(1);
+    // ---- phase 2.  The nearest candidate is measured first (16 bytes at a time); that sets the length to beat.  The rest
+    // are taken nearest first, LZ_POP of a mask register per pass: one whose byte at the best length so far differs
+    // cannot be longer and is dropped after that one LDS byte read -- the reference's own pruning test (:199-200), here
+    // issued for the whole batch so that the batch pays one LDS latency.  Survivors are measured in order, so that
+    // `len > best` keeps the nearest of equals ----
     uint32_t best = 2, besto = 0;
+    auto measure = [&](uint32_t qb) {
+      const uint32_t qd = qb >> 2, qs = qb & 3u;
+      const uint32_t e0 = win[(qd + 0u) * LZ_BLOCK], e1 = win[(qd + 1u) * LZ_BLOCK], e2 = win[(qd + 2u) * LZ_BLOCK],
+                     e3 = win[(qd + 3u) * LZ_BLOCK], e4 = win[(qd + 4u) * LZ_BLOCK];
+      uint32_t len = lz_common16(lz_alignbyte(e1, e0, qs), lz_alignbyte(e2, e1, qs), lz_alignbyte(e3, e2, qs), lz_alignbyte(e4, e3, qs),
+                                 T0, T1, T2, T3);
+      if (len == 16u)
+        while (len < lim && LZ_WIN8(qb + len) == LZ_WIN8(rel + len))
+          len++;
+      len = len < lim ? len : lim;
+      if (len > best)
+      {
+        best = len;
+        besto = rel - qb;
+      }
+    };
+    if (wave_any((cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) != 0))
+    {
+      int32_t r = cm[4] != 0 ? 4 : cm[3] != 0 ? 3 : cm[2] != 0 ? 2 : cm[1] != 0 ? 1 : cm[0] != 0 ? 0 : -1;
+      if (r >= 0)
+      {
+        const uint32_t m = r == 4 ? cm[4] : r == 3 ? cm[3] : r == 2 ? cm[2] : r == 1 ? cm[1] : cm[0];
+        const uint32_t bit = 31u - clz32(m);
+        const uint32_t cleared = m & ~(1u << bit);
+        cm[4] = r == 4 ? cleared : cm[4];
+        cm[3] = r == 3 ? cleared : cm[3];
+        cm[2] = r == 2 ? cleared : cm[2];
+        cm[1] = r == 1 ? cleared : cm[1];
+        cm[0] = r == 0 ? cleared : cm[0];
+        measure(4u * wd0 + 32u * (uint32_t)r + bit);
+      }
+    }
 #pragma unroll
     for (int r = 4; r >= 0; r--)
     {
       while (wave_any(cm[r] != 0 && best < lim))
       {
-        if (cm[r] != 0 && best < lim)
+        uint32_t m = best < lim ? cm[r] : 0u;
+        uint32_t qb[LZ_POP], got[LZ_POP];
+        const uint32_t b0 = best;
+        // the four bytes k0..k0+3 end at byte b0 (for b0 = 2, nothing measured yet, only bytes 0..2 count): a candidate
+        // that differs there is no longer than b0; one that agrees is, up to b0 = 6, certainly longer
+        const uint32_t k0 = (b0 > 3u ? b0 : 3u) - 3u, cmpmask = b0 < 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
+        uint32_t has = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_POP; k++)
         {
-          const uint32_t bit = 31u - clz32(cm[r]);
-          cm[r] &= ~(1u << bit);
-          const uint32_t i = 32u * (uint32_t)r + bit;
-          const uint32_t qb = 4u * wd0 + i; // window byte index of the candidate
-          if (LZ_WIN8(qb + best) == LZ_WIN8(rel + best))
+          has |= m != 0 ? 1u << k : 0u;
+          const uint32_t bit = 31u - clz32(m | 1u);
+          m &= ~(1u << bit);
+          qb[k] = 4u * wd0 + 32u * (uint32_t)r + bit; // window byte index of the candidate (a valid address also when there is none)
+          const uint32_t cb = qb[k] + k0;
+          got[k] = lz_alignbyte(win[((cb >> 2) + 1u) * LZ_BLOCK], win[(cb >> 2) * LZ_BLOCK], cb & 3u);
+        }
+        const uint32_t tb = rel + k0;
+        const uint32_t want = lz_alignbyte(win[((tb >> 2) + 1u) * LZ_BLOCK], win[(tb >> 2) * LZ_BLOCK], tb & 3u);
+        cm[r] = best < lim ? m : cm[r];
+        uint32_t surv = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < LZ_POP; k++)
+          surv |= ((got[k] ^ want) & cmpmask) == 0 ? 1u << k : 0u;
+        surv &= has;
+        while (wave_any(surv != 0))
+        {
+          if (surv != 0)
           {
-            const uint32_t qd = qb >> 2, qs = qb & 3u;
-            const uint32_t e0 = win[(qd + 0u) * LZ_BLOCK], e1 = win[(qd + 1u) * LZ_BLOCK], e2 = win[(qd + 2u) * LZ_BLOCK],
-                           e3 = win[(qd + 3u) * LZ_BLOCK], e4 = win[(qd + 4u) * LZ_BLOCK];
-            uint32_t len = lz_common16(lz_alignbyte(e1, e0, qs), lz_alignbyte(e2, e1, qs), lz_alignbyte(e3, e2, qs),
-                                       lz_alignbyte(e4, e3, qs), T0, T1, T2, T3);
-            if (len == 16u)
-              while (len < lim && LZ_WIN8(qb + len) == LZ_WIN8(rel + len))
-                len++;
-            len = len < lim ? len : lim;
-            if (len > best)
-            {
-              best = len;
-              besto = LZ_HISTORY + s - i;
-            }
+            const uint32_t k = (uint32_t)__builtin_ctz(surv);
+            surv &= surv - 1u;
+            uint32_t q = qb[0];
+#pragma unroll
+            for (uint32_t j = 1; j < LZ_POP; j++)
+              q = k == j ? qb[j] : q;
+            if (best < lim)
+              measure(q);
           }
         }
       }
     }
+    DG_STAMP(2);
     // a match that ran into the end of the window before the reference's own limit: reload around P and do the step again
     const bool again = search && best >= lim && lim < maxlen;
     if (again)
@@ -338,6 +395,7 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
       }
       P += best;
     }
+    DG_STAMP(3);
     if (wave_any(lit))
     {
       // literal: position of the symbol in the frequency list (lzmh.c:285-333)
@@ -363,14 +421,33 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
       {
         if (found != 0xFFFFu)
         {
-          const uint32_t c0 = LZ_CNT(found);
+          // the count, and the three entries in front of it, in one round of LDS reads: bubbling past more than three
+          // entries (all of them have the same count) is rare and continues one read at a time
+          const uint32_t p1 = found > 0 ? found - 1u : 0u, p2 = found > 1 ? found - 2u : 0u, p3 = found > 2 ? found - 3u : 0u;
+          const uint32_t c0 = LZ_CNT(found), c1 = LZ_CNT(p1), c2 = LZ_CNT(p2), c3 = LZ_CNT(p3);
+          const uint32_t s1 = LZ_SYM8(p1), s2 = LZ_SYM8(p2), s3 = LZ_SYM8(p3);
           if (c0 < 65535u)
           {
-            uint32_t i = found; // bubble towards the front past entries with a smaller count: only symbols move (:306-309)
-            while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+            uint32_t i = found; // towards the front past entries with a smaller count: only symbols move (:306-309)
+            if (i > 0 && c0 + 1u > c1)
             {
-              LZ_SYM8(i) = LZ_SYM8(i - 1u);
+              LZ_SYM8(i) = (uint8_t)s1;
               i--;
+              if (i > 0 && c0 + 1u > c2)
+              {
+                LZ_SYM8(i) = (uint8_t)s2;
+                i--;
+                if (i > 0 && c0 + 1u > c3)
+                {
+                  LZ_SYM8(i) = (uint8_t)s3;
+                  i--;
+                  while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+                  {
+                    LZ_SYM8(i) = LZ_SYM8(i - 1u);
+                    i--;
+                  }
+                }
+              }
             }
             LZ_CNT(i) = (uint16_t)(c0 + 1u);
             LZ_SYM8(i) = (uint8_t)sym;
@@ -393,6 +470,7 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
       }
     }
 
+    DG_STAMP(4);
     // ---- output: bits -> 64-bit accumulator -> staged words in LDS -> 16-byte stores ----
     if (emit)
     {
@@ -422,6 +500,7 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         staged = 0;
       }
     }
+    DG_STAMP(5);
   }
 
   // ---- finish: the staged words and the partial word, zero padded ----
@@ -443,6 +522,12 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
     }
     a.out_bits[c] = bits;
     a.err[c] = err;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+    if ((tid & 63u) < 8)
+      a.out_bits[c] = stamp_sum[tid & 63u];
+    else if ((tid & 63u) < 16)
+      a.out_bits[c] = stamp_cnt[(tid & 63u) - 8];
+#endif
   }
 #undef LZ_WIN8
 #undef LZ_SYM8

@@ -149,30 +149,32 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   int32_t *err = NULL;
   int32_t *x = NULL;
   size_t T, cap, c, t;
+  const size_t vs = options->value_size_bits;
+  const size_t in_vs = is_float ? 32 : vs; /* normalize always reads 32-bit floats (normalize.c:15) */
   io_int_t ret;
 
-  if (options->value_size_bits != 32)
+  if (vs < 1 || vs > 32)
   {
-    LOG_TO(log, "dega: only valuesize=32 is supported on the GPU path\n");
+    LOG_TO(log, "dega: valuesize 1..32 is supported on the GPU path (int32 sample containers)\n");
     return ERROR_INVALID_VALUE;
   }
   if ((ret = get_context(log, &ctx)) != NO_ERROR)
     return ret;
   if ((ret = slurp(in, &raw, &nbits)) != NO_ERROR)
     goto done;
-  if (nbits % 32 != 0) /* the reference's READ_VALUE_BITS_CHECKED would stop on the short last value */
+  if (nbits % in_vs != 0) /* the reference's READ_VALUE_BITS_CHECKED would stop on the short last value */
   {
-    LOG_TO(log, "Only read %lu bits instead of 32\n", (unsigned long)(nbits % 32));
+    LOG_TO(log, "Only read %lu bits instead of %lu\n", (unsigned long)(nbits % in_vs), (unsigned long)in_vs);
     ret = ERROR_LIBRARY_CALL;
     goto done;
   }
-  if ((nbits / 32) % C != 0)
+  if ((nbits / in_vs) % C != 0)
   {
-    LOG_TO(log, "dega: %lu values do not divide into %lu channels\n", (unsigned long)(nbits / 32), (unsigned long)C);
+    LOG_TO(log, "dega: %lu values do not divide into %lu channels\n", (unsigned long)(nbits / in_vs), (unsigned long)C);
     ret = ERROR_INVALID_VALUE;
     goto done;
   }
-  T = (size_t)(nbits / 32) / C;
+  T = (size_t)(nbits / in_vs) / C;
   cap = dega_hip_worst_case_bytes(T);
   streams = (uint8_t *)malloc(C * cap);
   bits = (uint64_t *)calloc(C, sizeof(uint64_t));
@@ -186,14 +188,25 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   if (is_float)
   {
     memcpy(x, raw.p, T * C * 4); /* raw native-endian float32, as `decode csv` writes them (csv.c:13-44) */
-    ret = dega_hip_encode_f32_host(ctx, (const float *)(const void *)x, C, T, C, options->normalization_factor, options->adaptive, 32,
+    ret = dega_hip_encode_f32_host(ctx, (const float *)(const void *)x, C, T, C, options->normalization_factor, options->adaptive, (int)vs,
                                    streams, cap, bits, err);
   }
   else
   {
-    for (t = 0; t < T * C; t++) /* big-endian values -> native int32 */
-      x[t] = (int32_t)(((uint32_t)raw.p[4 * t] << 24) | ((uint32_t)raw.p[4 * t + 1] << 16) | ((uint32_t)raw.p[4 * t + 2] << 8) | raw.p[4 * t + 3]);
-    ret = dega_hip_encode_host(ctx, x, C, T, C, options->adaptive, 32, streams, cap, bits, err);
+    if (vs == 32)
+      for (t = 0; t < T * C; t++) /* big-endian values -> native int32 */
+        x[t] = (int32_t)(((uint32_t)raw.p[4 * t] << 24) | ((uint32_t)raw.p[4 * t + 1] << 16) | ((uint32_t)raw.p[4 * t + 2] << 8) | raw.p[4 * t + 3]);
+    else
+      for (t = 0; t < T * C; t++) /* valuesize-bit values, MSB first, zero extended (diff.c:15 does not sign extend) */
+      {
+        const uint64_t at = (uint64_t)t * vs;
+        uint64_t w = 0;
+        size_t k;
+        for (k = 0; k < 5; k++)
+          w = (w << 8) | raw.p[(at >> 3) + k]; /* slurp() pads the buffer with 16 zero bytes */
+        x[t] = (int32_t)((w >> (40 - (at & 7) - vs)) & (((uint64_t)1 << vs) - 1));
+      }
+    ret = dega_hip_encode_host(ctx, x, C, T, C, options->adaptive, (int)vs, streams, cap, bits, err);
   }
   if (ret != DEGA_OK)
   {
@@ -262,12 +275,13 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   int32_t *err = NULL;
   int32_t *x = NULL;
   size_t C = 1, T = 0, cap = 0, c, t;
+  const size_t vs = options->value_size_bits;
   int known_T = 0;
   io_int_t ret;
 
-  if (options->value_size_bits != 32)
+  if (vs < 1 || vs > 32)
   {
-    LOG_TO(log, "dega: only valuesize=32 is supported on the GPU path\n");
+    LOG_TO(log, "dega: valuesize 1..32 is supported on the GPU path (int32 sample containers)\n");
     return ERROR_INVALID_VALUE;
   }
   if ((ret = get_context(log, &ctx)) != NO_ERROR)
@@ -353,11 +367,11 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
       goto done;
     }
     if (is_float)
-      ret = known_T ? dega_hip_decode_f32_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, 32, (float *)(void *)x, err)
-                    : dega_hip_decode_f32_var_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, 32, (float *)(void *)x, counts, err);
+      ret = known_T ? dega_hip_decode_f32_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, (int)vs, (float *)(void *)x, err)
+                    : dega_hip_decode_f32_var_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, (int)vs, (float *)(void *)x, counts, err);
     else
-      ret = known_T ? dega_hip_decode_host(ctx, streams, cap, bits, C, T, C, options->adaptive, 32, x, err)
-                    : dega_hip_decode_var_host(ctx, streams, cap, bits, C, T, C, options->adaptive, 32, x, counts, err);
+      ret = known_T ? dega_hip_decode_host(ctx, streams, cap, bits, C, T, C, options->adaptive, (int)vs, x, err)
+                    : dega_hip_decode_var_host(ctx, streams, cap, bits, C, T, C, options->adaptive, (int)vs, x, counts, err);
     if (ret != DEGA_OK)
     {
       LOG_TO(log, "dega: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_last_error(ctx));
@@ -384,7 +398,7 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
     else
     {
       const io_uint_t v = (uint32_t)x[t];
-      if (WriteSingleValueToBitFileBuffer(out, &v, 32) != 32)
+      if (WriteSingleValueToBitFileBuffer(out, &v, vs) != (io_int_t)vs)
         ret = ERROR_LIBRARY_CALL;
     }
   }

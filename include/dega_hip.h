@@ -16,7 +16,7 @@
  * is shown in INTEGRATION.md and implemented in data-compressor_amd/host/.
  *
  * Per channel the produced bytes and the exact bit length equal what the reference's chain
- *     encode diff # encode seg # encode bac [adaptive]        (valuesize 32)
+ *     encode diff # encode seg # encode bac [adaptive]        (valuesize 1..32)
  * produces for that channel alone; errors are per channel and use the reference's codes (common/inc/err_codes.h:8-32).
  *
  * Layouts
@@ -60,7 +60,11 @@ const char *dega_hip_version(void);
 size_t dega_hip_worst_case_bytes(size_t T);
 
 /* ---- DEGA encode / decode, device pointers ----------------------------------------------------------------------- */
-/* valuesize must be 32 (the only width the [T][C] int32 layout carries); adaptive: 0 = `bac`, 1 = `bac adaptive`. */
+/* valuesize: 1..32, the `valuesize` option of the three stages (DCLib/src/enc_dec.c:72).  A sample is the low valuesize
+   bits of its int32 container, read unsigned as diff.c:15 does; bits above are ignored on encode and zero on decode.
+   The difference must fit valuesize bits signed, else that channel reports ERROR_INVALID_VALUE (diff.c:17-18); the
+   decoder caps a codeword's zero prefix at valuesize + 1 (seg.c:55-56,74).  33..64 would need 64-bit containers: not
+   carried by this layout.  adaptive: 0 = `bac`, 1 = `bac adaptive`. */
 int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                         uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
 /* in_bits[c] is the exact bit length, or 8*bytes when the stream comes from a zero-padded file.  Decodes exactly T

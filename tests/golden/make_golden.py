@@ -13,6 +13,8 @@ Fixtures are data only (inputs + the reference's outputs):
   kats.json            known-answer vectors re-generated through the reference library
   channels.npz         small int32 channel batches [T][C] + the reference's per-channel DEGA streams
   floats.npz           float32 edge cases + the reference's normalize / denormalize results
+  valuesizes.npz       channel batches for valuesize 1..31 (unsigned valuesize-bit samples) + the reference's streams of
+                       `encode diff valuesize=n # encode seg valuesize=n # encode bac [adaptive]`, error channels included
   lzmh.json / lzmh.npz the reference's `encode lzmh` of the test file (size, bits, sha256) and of small byte strings
                        (meter CSV text, digits, binary, periodic; lengths around the 403-byte ring size)
 """
@@ -196,6 +198,58 @@ def floats():
     print("floats:", v.size, "edge rets", rets, "2^31:", ret, b.hex())
 
 
+def pack_be(vals, vs):
+    """unsigned values as vs-bit big-endian fields -> (bytes, nbits): what a stage reads with valuesize=vs"""
+    v = np.asarray(vals, dtype=np.uint64)
+    bits = np.zeros(len(v) * vs, dtype=np.uint8)
+    for k in range(vs):
+        bits[k::vs] = (v >> np.uint64(vs - 1 - k)) & np.uint64(1)
+    return np.packbits(bits).tobytes(), len(v) * vs
+
+
+def valuesizes():
+    rng = np.random.default_rng(31)
+    out = {}
+    for vs in (1, 2, 7, 8, 12, 15, 16, 17, 24, 31):
+        T, Cn = 160, 12
+        top = (1 << vs) - 1
+        x = np.zeros((T, Cn), dtype=np.int64)
+        for c in range(Cn):
+            kind = c % 4
+            if kind == 0:
+                col = np.clip(np.cumsum(rng.integers(-3, 4, T)) + top // 2, 0, top)
+            elif kind == 1:
+                col = rng.integers(0, top + 1, T)  # jumps beyond +-2^(vs-1): ERROR_INVALID_VALUE (diff.c:17-18)
+            elif kind == 2:
+                col = np.clip(np.cumsum(rng.integers(-(top // 8 + 1), top // 8 + 2, T)) + top // 2, 0, top)
+            else:
+                col = np.full(T, top // 3)
+            x[:, c] = col
+        out["vs%d.x" % vs] = x.astype(np.uint32)
+        for ad in (1, 0):
+            streams, bits, errs = [], [], []
+            opt = " valuesize=%d" % vs
+            for c in range(Cn):
+                data, n = pack_be(x[:, c], vs)
+                ret, b, nb, _ = orc.ref_run_chain(data, n, ["encode diff" + opt, "encode seg" + opt, "encode bac adaptive" if ad else "encode bac"])
+                streams.append(b if ret == 0 else b"")
+                bits.append(nb if ret == 0 else 0)
+                errs.append(ret)
+                if ret == 0:
+                    rd, d, dn, _ = orc.ref_run_chain(b, nb, ["decode bac adaptive" if ad else "decode bac", "decode seg" + opt, "decode diff" + opt])
+                    assert rd == 0 and (d[: (dn + 7) // 8], dn) == (data, n), (vs, c)
+            cap = max(1, max(len(s_) for s_ in streams))
+            arr = np.zeros((Cn, cap), dtype=np.uint8)
+            for c, s_ in enumerate(streams):
+                arr[c, : len(s_)] = np.frombuffer(s_, dtype=np.uint8)
+            tag = "vs%d.%s" % (vs, "ad" if ad else "st")
+            out[tag + ".stream"] = arr
+            out[tag + ".bits"] = np.array(bits, dtype=np.uint64)
+            out[tag + ".err"] = np.array(errs, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "valuesizes.npz"), **out)
+    print("valuesizes:", {k[:-7]: int((v != 0).sum()) for k, v in out.items() if k.endswith(".ad.err")}, "(channels in error)")
+
+
 def lzmh_inputs():
     """Deterministic byte strings for the LZMH fixtures (name -> bytes)."""
     rng = np.random.default_rng(11)
@@ -247,6 +301,10 @@ if __name__ == "__main__":
     if only == ["lzmh"]:
         lzmh()
         sys.exit(0)
+    if only == ["valuesizes"]:
+        valuesizes()
+        sys.exit(0)
     channels()
     floats()
+    valuesizes()
     lzmh()

@@ -25,40 +25,69 @@ static std::vector<uint32_t> make_table()
   return tab;
 }
 
-extern "C" __attribute__((visibility("default"))) int sim_encode(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
+extern "C" __attribute__((visibility("default"))) int sim_encode_vs(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, int valuesize, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
-  EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data()};
+  EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), (uint32_t)valuesize};
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-  if (adaptive)
+  if (valuesize < 32)
+  {
+    if (adaptive)
+      sim::launch(dega_encode_kernel<true, true>, grid, dim3(BLOCK), a);
+    else
+      sim::launch(dega_encode_kernel<false, true>, grid, dim3(BLOCK), a);
+  }
+  else if (adaptive)
     sim::launch(dega_encode_kernel<true>, grid, dim3(BLOCK), a);
   else
     sim::launch(dega_encode_kernel<false>, grid, dim3(BLOCK), a);
   return 0;
 }
 
-extern "C" __attribute__((visibility("default"))) int sim_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
+extern "C" __attribute__((visibility("default"))) int sim_encode(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
+{
+  return sim_encode_vs(x, C, T, ld, adaptive, 32, out, cap, bits, err);
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_decode_var_vs(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int valuesize, int32_t *x, uint64_t *counts, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
-  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr};
+  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), counts, (uint32_t)valuesize};
   const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-  if (adaptive)
+  if (valuesize < 32)
+  {
+    if (adaptive)
+      sim::launch(dega_decode_kernel<true, true>, grid, dim3(BLOCK), a);
+    else
+      sim::launch(dega_decode_kernel<false, true>, grid, dim3(BLOCK), a);
+  }
+  else if (adaptive)
     sim::launch(dega_decode_kernel<true>, grid, dim3(BLOCK), a);
   else
     sim::launch(dega_decode_kernel<false>, grid, dim3(BLOCK), a);
   return 0;
 }
 
+extern "C" __attribute__((visibility("default"))) int sim_decode_vs(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int valuesize, int32_t *x, int32_t *err)
+{
+  return sim_decode_var_vs(in, cap, in_bits, C, T, ld, adaptive, valuesize, x, nullptr, err);
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
+{
+  return sim_decode_var_vs(in, cap, in_bits, C, T, ld, adaptive, 32, x, nullptr, err);
+}
+
 extern "C" __attribute__((visibility("default"))) int sim_normalize(const float *v, size_t C, size_t T, size_t ld, float factor, int32_t *x, int32_t *err)
 {
-  NormalizeArgs a{v, x, C, T, ld, factor, err};
+  NormalizeArgs a{v, x, C, T, ld, factor, err, -2147483648.0f, 2147483648.0f, 0xFFFFFFFFu};
   sim::launch(dega_normalize_kernel, dim3((unsigned)((C + BLOCK - 1) / BLOCK), 2), dim3(BLOCK), a);
   return 0;
 }
 
 extern "C" __attribute__((visibility("default"))) int sim_denormalize(const int32_t *x, size_t C, size_t T, size_t ld, float factor, float *v)
 {
-  DenormalizeArgs a{x, v, C, T, ld, factor};
+  DenormalizeArgs a{x, v, C, T, ld, factor, 0u};
   sim::launch(dega_denormalize_kernel, dim3((unsigned)((C + BLOCK - 1) / BLOCK), 2), dim3(BLOCK), a);
   return 0;
 }

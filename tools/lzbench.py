@@ -35,6 +35,11 @@ n, ms = ctx.profile_read(2)
 nbytes = int(lens.sum().item())
 print("encode: %d channels, %.1f MB text, kernel %.3f ms (wall %.3f ms) -> %.2f GB/s, %.3f bits/byte, errors %d" % (
     C_, nbytes / 1e6, ms, dt * 1e3, nbytes / ms / 1e6, float(bits.sum().item()) / nbytes, int((err != 0).sum().item())), flush=True)
+if "diag32" in dca.LIB_PATH:
+    b = bits.cpu().numpy().reshape(-1, 64)
+    names = ["reload_check", "phase1", "phase2", "code_match", "literal", "output", "reload", "loop_top"]
+    print({names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}, "total", int(b[:, :8].sum(axis=1).mean()))
+    sys.exit(0)
 back = torch.zeros((C_, stride), dtype=torch.uint8, device="cuda")
 ctx.profile(True)
 back, blens, derr = ctx.lzmh_decode(out, bits, stride, out=back)
