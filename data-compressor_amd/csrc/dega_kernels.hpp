@@ -203,6 +203,8 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     issue_rows(0);
 
   uint32_t iter = 0;
+  uint32_t Mnext[32]; // division magics of the next fast word, see BacEncoder::fetch_magics
+  enc.fetch_magics(tab, Mnext);
   DG_STAMP_DECL;
   for (;;)
   {
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
         {
           const BacEncoder<ADAPTIVE> checkpoint = enc;
           if (fast)
-            done = enc.encode_word_fast(word, tab);
+            done = enc.encode_word_fast(word, Mnext);
           else if constexpr (ADAPTIVE)
             done = enc.encode_word_general(word, tab);
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 512)
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
       (void)general;
 #endif
     }
+    enc.fetch_magics(tab, Mnext); // for the next code step; in flight during fill and drain
     // ---- everything issued at the end of the previous iteration has landed by now ----------------------------------
     wait_vector_memory();
     DG_STAMP(5);
@@ -457,6 +460,8 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
   };
   request_refill();
 
+  uint32_t Mnext[32]; // division magics of the next fast word (BacDecoder::fetch_magics), read a phase ahead
+  dec.fetch_magics(tab, Mnext);
   DG_STAMP_DECL;
   for (;;)
   {
@@ -483,9 +488,9 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
           const BacDecoder<ADAPTIVE> checkpoint = dec;
           uint32_t bits = 0;
           if (fast)
-            done = dec.template decode_word<false>(in, tab, bits);
+            done = dec.template decode_word<false>(in, tab, Mnext, bits);
           else if constexpr (ADAPTIVE)
-            done = dec.template decode_word<true>(in, tab, bits); // halving / swap / shift change somewhere in the wave
+            done = dec.template decode_word<true>(in, tab, Mnext, bits); // halving / swap / shift change somewhere in the wave
           if (done)
           {
             sp.push(bits, 32);
@@ -522,6 +527,7 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
         }
       }
     }
+    dec.fetch_magics(tab, Mnext); // for the next code step; in flight during the parse and write phases
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
     if (any_can)
     {
@@ -545,21 +551,27 @@ __global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
     DG_STAMP(5);
     // ---- phase S: parse what is there --------------------------------------------------------------------------------
     {
-      // (1) the steady state, branch free: up to 4 short codewords per pass; a lane that cannot take one writes to a
-      //     spare slot of its sample column instead
+      // (1) the steady state, branch free: short codewords off the top of the window; a lane that cannot take one writes
+      //     to a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data and the window
+      //     up to 64 bits, so the first pass takes up to 6 -- which is all there is for nearly every wave -- and the rare
+      //     follow-up passes 2 each
+      auto take = [&]() {
+        uint32_t sample;
+        const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
+        const bool took = sp.take_short<NARROW>(allowed, sample);
+        sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
+        t_lane += took ? 1u : 0u;
+        return took;
+      };
       bool more = true;
+#pragma unroll
+      for (uint32_t k = 0; k < 6; k++)
+        more = take();
+      DG_STAMP(2);
       while (wave_any(more))
       {
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-        {
-          uint32_t sample;
-          const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
-          const bool took = sp.take_short<NARROW>(allowed, sample);
-          sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
-          t_lane += took ? 1u : 0u;
-          more = took;
-        }
+        more = take();
+        more = take();
         DG_STAMP(2);
       }
       // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;

@@ -375,22 +375,28 @@ struct BacEncoder
 
   // Codes the 32 bits of `word`; completed words go to the lane's LDS column (the kernel drains it afterwards).
   // Returns false if a carry ran past `prev` (the caller restores its checkpoint and redoes the word with encode_bit).
-  DG_DEV bool encode_word_fast(uint32_t word, const uint32_t *magic)
+  // The 32 division magics of the word that a lane would code next with encode_word_fast (cum[0] = tot .. tot+31).
+  // The kernel fetches them from LDS right after a code step, so that the (bank-conflicting, per-lane scattered) reads
+  // and their latency overlap the fill and drain phases instead of heading the next word.
+  DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
-    const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
     const uint32_t *const mg = magic + tot;
-    const uint32_t sh = div_shift(tot);
-    uint32_t *const op0 = oring + staged * 64u;
-    uint32_t *op = op0;
-    uint32_t ovf = 0;
-    uint32_t Mg[32]; // the 32 division magics of this word (cum[0] = tot .. tot+31), fetched from LDS up front
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
       Mg[i] = 0x40000000u + tot * 131u + i; // diagnostic build: no table reads
 #else
-      Mg[i] = mg[i];
+      Mg[i] = mg[i]; // past the table's end for tot > 16352: never used then (fast_ok() is false)
 #endif
+  }
+
+  DG_DEV bool encode_word_fast(uint32_t word, uint32_t (&Mg)[32])
+  {
+    const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
+    const uint32_t sh = div_shift(tot);
+    uint32_t *const op0 = oring + staged * 64u;
+    uint32_t *op = op0;
+    uint32_t ovf = 0;
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
       DG_MATERIALISE(Mg[i]);
@@ -806,18 +812,19 @@ struct BacDecoder
   // stream bits (the 32-bit look-ahead is rebuilt every 4 symbols), or if the word needed more than the 4 staged words.
   // GENERAL = false: no model event (halving, MPS/LPS swap, division-shift change) can occur in the word (fast_ok()).
   // GENERAL = true : the whole model update of bac.c:54-81 by selects, as in BacEncoder::encode_word_general.
-  template <bool GENERAL, uint32_t IRING>
-  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t &bits_out)
+  // as BacEncoder::fetch_magics: the kernel issues these reads a phase early
+  DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
     const uint32_t *const mg = magic + tot;
-    const uint32_t sh_fast = div_shift(tot);
-    uint32_t Mg[32];
-    if (!GENERAL)
-    {
 #pragma unroll
-      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-        Mg[i] = mg[i];
-    }
+    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+      Mg[i] = mg[i];
+  }
+
+  template <bool GENERAL, uint32_t IRING>
+  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t (&Mg)[32], uint32_t &bits_out)
+  {
+    const uint32_t sh_fast = div_shift(tot);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
     const uint32_t w0 = in.word(k0), w1 = in.word(k0 + 1u), w2 = in.word(k0 + 2u), w3 = in.word(k0 + 3u);

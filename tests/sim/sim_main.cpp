@@ -13,7 +13,7 @@ using namespace dg;
 
 static std::vector<uint32_t> make_table()
 {
-  std::vector<uint32_t> tab(DIV_TABLE_SIZE, 0u);
+  std::vector<uint32_t> tab(DIV_TABLE_SIZE + 32, 0u); // + the look-ahead of BacEncoder::fetch_magics
   for (uint32_t t = 3; t < DIV_TABLE_SIZE; t++)
   {
     uint32_t L = 0;
@@ -167,10 +167,12 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_ta
       (*fast_taken)++;
       const BacEncoder<ADAPTIVE> ck = f;
       bool done;
+      uint32_t Mg[32];
+      f.fetch_magics(tab.data(), Mg);
       if constexpr (ADAPTIVE)
-        done = use_general ? f.encode_word_general(word, tab.data()) : f.encode_word_fast(word, tab.data());
+        done = use_general ? f.encode_word_general(word, tab.data()) : f.encode_word_fast(word, Mg);
       else
-        done = f.encode_word_fast(word, tab.data());
+        done = f.encode_word_fast(word, Mg);
       if (!done)
       {
         (*redo_taken)++;
