@@ -25,6 +25,7 @@ struct dega_hip_ctx
   bool profile;
   std::vector<hipEvent_t> ev[4]; // start/stop pairs per kernel kind (0 encode, 1 decode, 2 lzmh encode, 3 lzmh decode)
   std::vector<hipEvent_t> ev_pool;
+  int force_waves; // 0 = choose by batch size; 4 / 8 = DEGA_WAVES_PER_WORKGROUP (measurement knob)
 };
 
 static int fail(dega_hip_ctx *ctx, int code, const char *what, hipError_t e)
@@ -90,6 +91,11 @@ extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
   ctx->div_magic = nullptr;
   ctx->last_error[0] = '\0';
   ctx->profile = false;
+  {
+    const char *w = getenv("DEGA_WAVES_PER_WORKGROUP");
+    const int v = w != nullptr ? atoi(w) : 0;
+    ctx->force_waves = (v == 4 || v == 8) ? v : 0;
+  }
   if (hipSetDevice(device) != hipSuccess)
   {
     delete ctx;
@@ -236,21 +242,39 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   a.err = err;
   a.div_magic = ctx->div_magic;
   a.valuesize = (uint32_t)valuesize;
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 0, s);
-    if (valuesize < 32) // the narrow variants mask the samples and range check against the value size
+    if (ctx->force_waves == 8 || (ctx->force_waves == 0 && C > 65536)) // more than one wave per SIMD of work: 8-wave workgroups with smaller rings, two waves per SIMD
     {
-      if (adaptive)
-        hipLaunchKernelGGL((dega_encode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+      const dim3 grid((unsigned)((C + 511) / 512)), block(512);
+      if (valuesize < 32)
+      {
+        if (adaptive)
+          hipLaunchKernelGGL((dega_encode_kernel<true, true, 8, 4, 16, 24>), grid, block, 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_encode_kernel<false, true, 8, 4, 16, 24>), grid, block, 0, s, a);
+      }
+      else if (adaptive)
+        hipLaunchKernelGGL((dega_encode_kernel<true, false, 8, 4, 16, 24>), grid, block, 0, s, a);
       else
-        hipLaunchKernelGGL((dega_encode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_encode_kernel<false, false, 8, 4, 16, 24>), grid, block, 0, s, a);
     }
-    else if (adaptive)
-      hipLaunchKernelGGL(dega_encode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
     else
-      hipLaunchKernelGGL(dega_encode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+    {
+      const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+      if (valuesize < 32) // the narrow variants mask the samples and range check against the value size
+      {
+        if (adaptive)
+          hipLaunchKernelGGL((dega_encode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_encode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+      }
+      else if (adaptive)
+        hipLaunchKernelGGL(dega_encode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL(dega_encode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+    }
   }
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
@@ -277,21 +301,39 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
   a.div_magic = ctx->div_magic;
   a.out_count = out_count;
   a.valuesize = (uint32_t)valuesize;
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 1, s);
-    if (valuesize < 32)
+    if (ctx->force_waves == 8 || (ctx->force_waves == 0 && C > 65536)) // more than one wave per SIMD of work: 8-wave workgroups, two waves per SIMD
     {
-      if (adaptive)
-        hipLaunchKernelGGL((dega_decode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+      const dim3 grid((unsigned)((C + 511) / 512)), block(512);
+      if (valuesize < 32)
+      {
+        if (adaptive)
+          hipLaunchKernelGGL((dega_decode_kernel<true, true, 8>), grid, block, 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_decode_kernel<false, true, 8>), grid, block, 0, s, a);
+      }
+      else if (adaptive)
+        hipLaunchKernelGGL((dega_decode_kernel<true, false, 8>), grid, block, 0, s, a);
       else
-        hipLaunchKernelGGL((dega_decode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_decode_kernel<false, false, 8>), grid, block, 0, s, a);
     }
-    else if (adaptive)
-      hipLaunchKernelGGL(dega_decode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
     else
-      hipLaunchKernelGGL(dega_decode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+    {
+      const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+      if (valuesize < 32)
+      {
+        if (adaptive)
+          hipLaunchKernelGGL((dega_decode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_decode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
+      }
+      else if (adaptive)
+        hipLaunchKernelGGL(dega_decode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL(dega_decode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
+    }
   }
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;

@@ -121,7 +121,7 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
 {
   if (ADAPTIVE)
   {
-    for (uint32_t i = threadIdx.x; i < DIV_TABLE_SIZE; i += BLOCK)
+    for (uint32_t i = threadIdx.x; i < DIV_TABLE_SIZE; i += blockDim.x)
       tab[i] = gtab[i];
   }
   else if (threadIdx.x < 4)
@@ -129,31 +129,37 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
   __syncthreads();
 }
 
-template <bool ADAPTIVE, bool NARROW = false>
-__global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
+// NW waves per workgroup, ROWS rows per fill batch, RING / ORING words of seg-bit / output ring per lane.  Two shapes are
+// instantiated: <4, 8, 32, 32> -- one wave per SIMD, for batches of up to 64 Ki channels (all the waves there are) -- and
+// <8, 4, 16, 24> for larger batches: eight waves share the table, the smaller rings keep the workgroup within the CU's
+// LDS (154 KiB), and the second wave of each SIMD fills the issue slots the first leaves empty while it waits.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING>
+__global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a)
 {
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
+  constexpr uint32_t FILL_WORDS = (31 + 65 * ROWS) / 32; // most words a batch can add (65-bit worst-case codewords)
+  static_assert(FILL_WORDS < RING && ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
   const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
   // access with a vmcnt(0) wait):  division magics (64 KiB) | seg-bit rings | coded-word rings | input rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  __shared__ uint32_t lds[TAB_WORDS + WAVES * (ENC_RING + ENC_ORING + ENC_ROWS) * 64];
+  __shared__ uint32_t lds[TAB_WORDS + NW * (RING + ORING + ROWS) * 64];
   uint32_t *const tab = lds;
   uint32_t *const ring = tab + TAB_WORDS;              // seg bits waiting to be coded, per lane
-  uint32_t *const oring = ring + WAVES * ENC_RING * 64;  // coded words waiting to be stored, per lane
-  uint32_t *const xrows = oring + WAVES * ENC_ORING * 64; // the next input rows, per lane
+  uint32_t *const oring = ring + NW * RING * 64;  // coded words waiting to be stored, per lane
+  uint32_t *const xrows = oring + NW * ORING * 64; // the next input rows, per lane
 
   load_div_table<ADAPTIVE>(tab, a.div_magic);
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * (NW * 64u) + threadIdx.x;
   const bool live = c < a.C;
-  uint32_t *const ring_col = &ring[wave * ENC_RING * 64 + lane];
+  uint32_t *const ring_col = &ring[wave * RING * 64 + lane];
 
-  BacEncoder<ADAPTIVE> enc;
+  BacEncoder<ADAPTIVE, ORING> enc;
   enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u,
-           &oring[wave * ENC_ORING * 64 + lane]);
+           &oring[wave * ORING * 64 + lane]);
   BitQueue q;
   q.init();
   uint32_t last = 0; // diff.c:11
@@ -165,24 +171,24 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
   // sits right after the NEXT iteration's code step, ~6000 cycles later, when everything has long retired.  (vmcnt
   // retires in order: with register loads hipcc placed vmcnt(0) waits right behind the drain's stores -- 26 % of all
   // cycles -- and copied freshly loaded registers at the loop's back edge.)
-  uint32_t *const rows_wave = &xrows[wave * ENC_ROWS * 64]; // wave uniform
+  uint32_t *const rows_wave = &xrows[wave * ROWS * 64]; // wave uniform
   const uint32_t *const rows_col = rows_wave + lane;
-  size_t t = 0; // rows consumed by fills, wave uniform; after the wait LDS holds rows [t, t + ENC_ROWS)
+  size_t t = 0; // rows consumed by fills, wave uniform; after the wait LDS holds rows [t, t + ROWS)
   const size_t t_last = a.T > 0 ? a.T - 1 : 0;
   const int32_t *const last_row = a.x + t_last * a.ld;
   const uint32_t col_idx = live ? (uint32_t)c : 0u; // C <= 2^32 columns
 
   // When the wave's 64 channels all exist and rows are 16-byte aligned, one LDS-DMA instruction fetches FOUR rows:
   // lanes 16r .. 16r+15 read row r's 256 bytes as 16-byte pieces, which land as row r of the [row][64] LDS image.
-  const size_t c_wave0 = (size_t)blockIdx.x * BLOCK + wave * 64u;
-  const bool rows_x4 = (ENC_ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
-  auto issue_rows = [&](size_t t0) // rows [t0, t0 + ENC_ROWS), clamped to the last row
+  const size_t c_wave0 = (size_t)blockIdx.x * (NW * 64u) + wave * 64u;
+  const bool rows_x4 = (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
+  auto issue_rows = [&](size_t t0) // rows [t0, t0 + ROWS), clamped to the last row
   {
     if (rows_x4)
     {
       const uint32_t r = lane >> 4, q = lane & 15u;
 #pragma unroll
-      for (uint32_t j = 0; j < ENC_ROWS / 4; j++)
+      for (uint32_t j = 0; j < ROWS / 4; j++)
       {
         const size_t row = t0 + 4 * j + r < a.T ? t0 + 4 * j + r : t_last;
         dma_x4_to_lds(a.x + row * a.ld + c_wave0 + q * 4u, rows_wave + j * 256u, lane);
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     }
     const int32_t *rowp = a.x + t0 * a.ld; // wave uniform; the lane adds its 32-bit column index
 #pragma unroll
-    for (uint32_t i = 0; i < ENC_ROWS; i++)
+    for (uint32_t i = 0; i < ROWS; i++)
     {
       const int32_t *const r = t0 + i < a.T ? rowp : last_row;
       if (live)
@@ -226,12 +232,12 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
 #endif
       if (has)
       {
-        const uint32_t word = ring_col[(q.rd % ENC_RING) * 64u];
+        const uint32_t word = ring_col[(q.rd % RING) * 64u];
         q.rd++;
         bool done = false;
         if (fast || general)
         {
-          const BacEncoder<ADAPTIVE> checkpoint = enc;
+          const BacEncoder<ADAPTIVE, ORING> checkpoint = enc;
           if (fast)
             done = enc.encode_word_fast(word, Mnext);
           else if constexpr (ADAPTIVE)
@@ -261,33 +267,33 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     // ---- everything issued at the end of the previous iteration has landed by now ----------------------------------
     wait_vector_memory();
     DG_STAMP(5);
-    // ---- phase F: the same ENC_ROWS rows for every lane ----------------------------------------------------------
-    const bool room = (q.wr - q.rd) + ENC_FILL_WORDS <= ENC_RING;
+    // ---- phase F: the same ROWS rows for every lane ----------------------------------------------------------
+    const bool room = (q.wr - q.rd) + FILL_WORDS <= RING;
     const bool fill = t < a.T && wave_all(room);
     DG_STAMP(0);
     if (fill)
     {
       const size_t left = a.T - t;
-      uint32_t xr[ENC_ROWS];
+      uint32_t xr[ROWS];
 #pragma unroll
-      for (uint32_t i = 0; i < ENC_ROWS; i++)
+      for (uint32_t i = 0; i < ROWS; i++)
         xr[i] = NARROW ? rows_col[i * 64u] & vmask : rows_col[i * 64u];
 #pragma unroll
-      for (uint32_t i = 0; i < ENC_ROWS; i++)
+      for (uint32_t i = 0; i < ROWS; i++)
         DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
       // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
-      uint32_t w[ENC_ROWS];
+      uint32_t w[ROWS];
       uint32_t last_try = last;
       bool all_ok = true, any_wide = false;
 #pragma unroll
-      for (uint32_t i = 0; i < ENC_ROWS; i++)
+      for (uint32_t i = 0; i < ROWS; i++)
       {
         bool ok, wide;
         w[i] = diff_seg_short<NARROW>(xr[i], last_try, ok, wide, vhalf);
         all_ok = all_ok && ok;
         any_wide = any_wide || wide;
       }
-      if (left >= ENC_ROWS && !wave_any(any_wide && live))
+      if (left >= ROWS && !wave_any(any_wide && live))
       {
         // the steady state: a full batch of short codewords, straight-line appends
         if (live)
@@ -296,26 +302,26 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
           if (!all_ok && lane_err == OK)
             lane_err = ERR_INVALID_VALUE;
 #pragma unroll
-          for (uint32_t i = 0; i < ENC_ROWS; i++)
-            q.put_short<ENC_RING>(w[i], ring_col);
+          for (uint32_t i = 0; i < ROWS; i++)
+            q.put_short<RING>(w[i], ring_col);
         }
       }
       else if (live)
       {
         // first samples of a channel, jumps, the last partial batch: the general three-piece writer, row by row
 #pragma unroll
-        for (uint32_t i = 0; i < ENC_ROWS; i++)
+        for (uint32_t i = 0; i < ROWS; i++)
         {
           if (i < left)
           {
             const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
             if (!sw.ok && lane_err == OK)
               lane_err = ERR_INVALID_VALUE;
-            q.put_codeword<ENC_RING>(sw, ring_col);
+            q.put_codeword<RING>(sw, ring_col);
           }
         }
       }
-      t += left < ENC_ROWS ? left : ENC_ROWS;
+      t += left < ROWS ? left : ROWS;
       DG_STAMP(1);
       if (t < a.T)
         issue_rows(t); // in flight during the next code step
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(256) dega_encode_kernel(const EncodeArgs a)
     // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
     // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
     iter++;
-    if ((iter % ENC_DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ENC_ORING))
+    if ((iter % ENC_DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
     {
       uint32_t base = 0; // first staged slot not yet stored
       while (wave_any(enc.staged - base >= 4u))
@@ -402,18 +408,20 @@ struct DecodeArgs
   uint32_t valuesize;  // 1..32: samples come out as the low valuesize bits, zero extended (diff.c:34)
 };
 
-template <bool ADAPTIVE, bool NARROW = false>
-__global__ void __launch_bounds__(256) dega_decode_kernel(const DecodeArgs a)
+// NW = waves per workgroup: 4 (one per SIMD) for batches of up to 64 Ki channels, 8 for larger ones -- two waves per SIMD
+// fill the issue slots a lone wave leaves empty while it waits on LDS or memory (the LDS budget allows it: 138 KiB)
+template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES>
+__global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
   constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + DEC_SRING + 1) * 64; // + a spare sample slot
-  __shared__ uint32_t lds[TAB_WORDS + WAVES * PER_WAVE];
+  __shared__ uint32_t lds[TAB_WORDS + NW * PER_WAVE];
   uint32_t *const tab = lds;
   load_div_table<ADAPTIVE>(tab, a.div_magic);
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t c = (size_t)blockIdx.x * (NW * 64u) + threadIdx.x;
   const bool live = c < a.C;
   uint32_t *const wave_lds = lds + TAB_WORDS + wave * PER_WAVE;
   uint32_t *const iring = wave_lds + lane;                               // staged stream words

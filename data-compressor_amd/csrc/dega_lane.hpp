@@ -156,7 +156,7 @@ DG_DEV uint32_t div_shift(uint32_t t)
 constexpr uint32_t ENC_WORD_MAX_OUT = 16; // the most one 32-symbol word can complete (32 * 16 bits)
 constexpr uint32_t ENC_ORING = 32;        // staged output words per lane; word paths need ENC_WORD_MAX_OUT free slots
 
-template <bool ADAPTIVE>
+template <bool ADAPTIVE, uint32_t ORING = ENC_ORING>
 struct BacEncoder
 {
   uint32_t A, B;
@@ -235,7 +235,7 @@ struct BacEncoder
 
   DG_DEV void push_word(uint32_t word)
   {
-    if (staged == ENC_ORING)
+    if (staged == ORING)
       drain_lane();
     oring[staged * 64u] = word;
     staged++;
@@ -363,7 +363,7 @@ struct BacEncoder
   // Preconditions for encode_word_fast on this lane (evaluated once per word):
   DG_DEV bool fast_ok() const
   {
-    bool ok = pos >= 1 && staged + ENC_WORD_MAX_OUT <= ENC_ORING; // a held-back word exists; room in the LDS column
+    bool ok = pos >= 1 && staged + ENC_WORD_MAX_OUT <= ORING; // a held-back word exists; room in the LDS column
     if (ADAPTIVE)
     {
       ok = ok && tot + 32u <= MAX_FREQUENCY;                  // no halving during these 32 updates
@@ -463,7 +463,7 @@ struct BacEncoder
   // power of two in cum[0] (the division shift changes).  Costs ~1.5x the fast path instead of ~3x for encode_bit.
   DG_DEV bool general_ok() const
   {
-    return pos >= 1 && staged + ENC_WORD_MAX_OUT <= ENC_ORING;
+    return pos >= 1 && staged + ENC_WORD_MAX_OUT <= ORING;
   }
 
   DG_DEV bool encode_word_general(uint32_t word, const uint32_t *magic)

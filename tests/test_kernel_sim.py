@@ -111,3 +111,34 @@ def test_decode_kernel_logic_on_golden_sets(sim):
             err = np.zeros(s2.shape[0], dtype=np.int32)
             sim.sim_decode(s2.ctypes.data, s2.shape[1], bits.ctypes.data, s2.shape[0], T, s2.shape[0], ad, y.ctypes.data, err.ctypes.data)
             assert (err == 0).all() and (y == x[:, ok]).all(), (name, tag)
+
+
+def test_wide_workgroup_shape_on_golden_sets(sim):
+    """The 8-wave workgroups (4-row fills, 16/24-word rings) the library uses for batches of more than 64 Ki channels,
+    forced on the small golden batches: same streams, same samples back."""
+    sig_e = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    sig_d = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    sim.sim_encode_wide.argtypes = sig_e
+    sim.sim_decode_wide.argtypes = sig_d
+    z = np.load(os.path.join(GOLDEN, "channels.npz"))
+    for name in ("walk300_T96", "wild", "with_errors", "ragged_small"):
+        x = np.ascontiguousarray(z[name + ".x"], dtype=np.int32)
+        T, Cn = x.shape
+        for ad, tag in ((1, "ad"), (0, "st")):
+            cap = (orc.lib().orc_dega_worst_case_bytes(T) + 3) & ~3
+            out = np.zeros((Cn, cap), dtype=np.uint8)
+            bits = np.zeros(Cn, dtype=np.uint64)
+            err = np.zeros(Cn, dtype=np.int32)
+            sim.sim_encode_wide(x.ctypes.data, Cn, T, Cn, ad, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+            gs, gb, ge = z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)], z["%s.%s.err" % (name, tag)]
+            assert (err == ge).all(), name
+            ok = ge == 0
+            assert (bits[ok] == gb[ok]).all(), name
+            for c in np.nonzero(ok)[0]:
+                nb = (int(gb[c]) + 7) // 8
+                assert out[c, :nb].tobytes() == gs[c, :nb].tobytes(), (name, tag, c)
+            y = np.zeros((T, Cn), dtype=np.int32)
+            derr = np.zeros(Cn, dtype=np.int32)
+            b2 = np.where(ok, bits, 0).astype(np.uint64)
+            sim.sim_decode_wide(out.ctypes.data, cap, b2.ctypes.data, Cn, T, Cn, ad, y.ctypes.data, derr.ctypes.data)
+            assert (derr[ok] == 0).all() and (y[:, ok] == x[:, ok]).all(), (name, tag)
