@@ -266,7 +266,7 @@ def lzmh_cpu_baseline(texts, gpu_out, gpu_bits):
             mismatches += 1
     dt = time.perf_counter() - t0
     return {"value": round(nbytes / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": "%d channels (%d bytes of ASCII) of the same workload, encode lzmh per channel, %.1f s" % (len(texts), nbytes, dt),
+            "sample": "%d channels (%d bytes) of the same workload, encode lzmh per channel, %.1f s" % (len(texts), nbytes, dt),
             "gpu_streams_bit_exact": mismatches == 0}
 
 

@@ -108,6 +108,16 @@ DG_DEV void add64_count_carry(uint64_t &W, uint64_t add, uint32_t &carries)
 #endif
 }
 
+// (acc << 1) | (x >> 31) in one instruction (funnel shift)
+DG_DEV uint32_t shift_in_msb(uint32_t acc, uint32_t x)
+{
+#if defined(DEGA_SIM)
+  return (acc << 1) | (x >> 31);
+#else
+  return __builtin_amdgcn_alignbit(acc, x, 31);
+#endif
+}
+
 // (~x) >> 16 in one instruction (SDWA: NOT of the high word, written zero-extended)
 DG_DEV uint32_t not_hi16(uint32_t x)
 {
@@ -863,12 +873,12 @@ struct BacDecoder
       const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
       const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
       const uint32_t lm = (uint32_t)((int32_t)(D - x1) >> 31); // all ones unless index 1 (D, x1 < 2^17)
-      eof = (eof << 1) | (D < x2 ? 1u : 0u);
       const uint32_t inc = select32(lm, x2, x1);
       B = select32(lm, 0u - (A + (x1 << 16)), B);
       A += inc << 16;
       D -= inc;
-      out = (out << 1) | ((lm ^ mm) & 1u);
+      eof |= D; // D < x2 (the EOF symbol, index 3) leaves D negative: the sign bit sticks, the word is redone bit by bit
+      out = GENERAL ? (out << 1) | ((lm ^ mm) & 1u) : shift_in_msb(out, lm); // fast word: lm now, mm once at the end
       if (GENERAL)
       {
         const uint32_t tie = (c1u - 1u == totu - c1u) ? 0xFFFFFFFFu : 0u;
@@ -896,13 +906,13 @@ struct BacDecoder
         ahead = o ? (lo << o) | (hi >> (32u - o)) : lo;
       }
     }
-    bits_out = out;
+    bits_out = GENERAL ? out : out ^ mm;
     bp = (uint64_t)k0 * 32u + off;
     if (GENERAL)
       mps = mm & 1u;
     else if (ADAPTIVE)
       tot += 32u;
-    return (eof | bad) == 0;
+    return (int32_t)eof >= 0 && bad == 0;
   }
 };
 

@@ -142,6 +142,37 @@ DG_DEV uint32_t lz_list_code(uint32_t p, uint32_t &len)
   return code;
 }
 
+// the inverse: list position from the top 8 bits t >= 0x80 of the code register.  The 19 codes are a complete prefix
+// code (4 x 4 bits 11xx, 5 x 5 bits 10011..10111, 4 x 6 bits 100010..100101, 2 x 7 bits, 4 x 8 bits), so the
+// reference's scan over the table (lzmh.c:421-446) finds exactly this entry -- or none, when fewer bits are left than the
+// code is long, which the caller checks
+DG_DEV uint32_t lz_list_position(uint32_t t, uint32_t &len)
+{
+  uint32_t p = 15u + (0x83u - t);
+  len = 8;
+  if (t >= 0x84u)
+  {
+    p = 13u + (0x43u - (t >> 1));
+    len = 7;
+  }
+  if (t >= 0x88u)
+  {
+    p = 9u + (0x25u - (t >> 2));
+    len = 6;
+  }
+  if (t >= 0x98u)
+  {
+    p = 4u + (0x17u - (t >> 3));
+    len = 5;
+  }
+  if (t >= 0xC0u)
+  {
+    p = 0x0Fu - (t >> 4);
+    len = 4;
+  }
+  return p;
+}
+
 __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a)
 {
   __shared__ uint32_t lds[LZ_LDS_DW];
@@ -590,6 +621,8 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
   uint32_t code_sym = 0;
   int32_t code_length = 0;
   uint32_t hp = 0, mru = 0;
+  uint32_t nvalid = 0; // entries 0 .. nvalid-1 of the list are in use (count > 0), entry nvalid is the first free one
+  const uint32_t *const symd = lds + LZD_OFF_SYM + tid;
   uint64_t obuf = 0;
   uint32_t nob = 0;
   uint64_t olen = 0;
@@ -650,18 +683,10 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
       }
       if ((code_sym & 0x80000000u) != 0) // list code
       {
-        uint32_t i = LZ_TREE, len = 0;
-        for (uint32_t p = 0; p < LZ_TREE; p++)
-        {
-          uint32_t l;
-          const uint32_t code = lz_list_code(p, l);
-          if (code_length >= (int32_t)l && (code_sym >> (32u - l)) == code)
-          {
-            i = p;
-            len = l;
-            break;
-          }
-        }
+        uint32_t len;
+        uint32_t i = lz_list_position(code_sym >> 24, len);
+        if (code_length < (int32_t)len)
+          i = LZ_TREE; // the code is cut off by the end of the stream: no table entry matches (lzmh.c:423)
         if (i == LZ_TREE)
           break; // unknown code: the reference returns NO_ERROR here
         const uint32_t sym = LZ_SYM8(i);
@@ -678,6 +703,9 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
           }
           LZ_CNT(i) = (uint16_t)(c0 + 1u);
           LZ_SYM8(i) = (uint8_t)sym;
+          if (i == nvalid) // only a damaged stream names an entry that is not in use yet
+            for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
+              ;
         }
       }
       else if ((code_sym & 0x40000000u) == 0) // 00 + byte
@@ -686,9 +714,19 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
         code_length -= 10;
         code_sym <<= 10;
         LZ_EMIT(sym);
-        uint32_t i = 0;
-        while (i < LZ_LIST && LZ_CNT(i) > 0 && LZ_SYM8(i) != sym)
-          i++;
+        // the reference walks the list until the symbol or the first unused entry (:463-465); here the symbol dwords are
+        // searched byte-parallel in one round of LDS reads and the first unused entry is known (nvalid)
+        uint32_t i = nvalid;
+        {
+          const uint32_t splat = sym * 0x01010101u;
+#pragma unroll
+          for (uint32_t k = LZ_SYM_DW; k-- > 0;)
+          {
+            const uint32_t z = lz_zero_bytes_exact(symd[k * LZ_BLOCK] ^ splat);
+            const uint32_t p = 4u * k + ((uint32_t)__builtin_ctz(z | 0x80000000u) >> 3);
+            i = (z != 0 && p < i) ? p : i; // a hit at or above nvalid is a stale byte
+          }
+        }
         if (i < LZ_LIST)
         {
           const uint32_t c0 = LZ_CNT(i);
@@ -702,6 +740,9 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
             }
             LZ_CNT(i) = (uint16_t)(c0 + 1u);
             LZ_SYM8(i) = (uint8_t)sym;
+            if (i == nvalid)
+              for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
+                ;
           }
         }
       }
@@ -774,11 +815,25 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
             code_sym <<= 9;
           }
         }
-        for (uint32_t k = 0; k < length && err == OK; k++)
+        if (offset >= 4u)
         {
-          const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
-          LZ_EMIT(sym);
+          // four bytes per LDS round trip: the source cannot overlap what these four positions write
+          const uint32_t *const histd = lds + LZD_OFF_HIST + tid;
+          for (uint32_t k = 0; k < length && err == OK; k += 4u)
+          {
+            const uint32_t from = (hp - offset) & (LZ_HISTORY - 1u);
+            const uint32_t v = lz_alignbyte(histd[(((from >> 2) + 1u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK], histd[(from >> 2) * LZ_BLOCK], from & 3u);
+            const uint32_t n = length - k < 4u ? length - k : 4u;
+            for (uint32_t j = 0; j < n; j++)
+              LZ_EMIT((v >> (8u * j)) & 0xFFu);
+          }
         }
+        else
+          for (uint32_t k = 0; k < length && err == OK; k++)
+          {
+            const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
+            LZ_EMIT(sym);
+          }
       }
     } while (err == OK && (ip < nbits || code_sym > 0));
 

@@ -249,3 +249,38 @@ def test_gpu_stream_ending_after_a_delimiter():
     ctx = dca.Context(0)
     _check_delimiter_cases(lambda data, bits, room: ctx.decode_var_host(data, bits, room, adaptive=1))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_valuesize_large_batch_wide_workgroups():
+    """More than 64 Ki channels take the 8-wave workgroup shape; with a narrow value size that is its own instantiation
+    of both kernels.  A sample of channels against the oracle's chain, all of them through the round trip."""
+    import torch
+    from __graft_entry__ import load_package
+    dca = load_package()
+    ctx = dca.Context(0)
+    rng = np.random.default_rng(12)
+    for vs, ad in ((16, 1), (9, 0)):
+        Cn, T = 70000, 48
+        half = 1 << (vs - 1)
+        x = (np.cumsum(rng.integers(-(half // 16 + 1), half // 16 + 2, (T, Cn)), axis=0) + half // 2).clip(0, (1 << vs) - 1).astype(np.int32)
+        xt = torch.from_numpy(x).cuda()
+        out, bits, err = ctx.encode(xt, adaptive=ad, valuesize=vs)
+        y, derr = ctx.decode(out, torch.where(err == 0, bits, torch.zeros_like(bits)), T, adaptive=ad, valuesize=vs)
+        torch.cuda.synchronize()
+        e = err.cpu().numpy()
+        ok = e == 0
+        assert ok.sum() > Cn // 2  # most walks stay inside +-2^(valuesize-1) per step; the clipped ones may not
+        assert (derr.cpu().numpy()[ok] == 0).all() and (y.cpu().numpy()[:, ok] == x[:, ok]).all()
+        ob, bb = out.cpu().numpy(), bits.cpu().numpy()
+        for c in list(range(0, Cn, 997)) + [Cn - 1]:
+            d, n = pack_be(x[:, c], vs)
+            r = 0
+            for name in ("diff", "seg", "bac"):
+                r, d, n = orc.stage(name, True, d, n, valuesize=vs, adaptive=ad)
+                if r != 0:
+                    break
+            assert e[c] == r, (vs, c)
+            if r == 0:
+                assert int(bb[c]) == n and ob[c, : (n + 7) // 8].tobytes() == d[: (n + 7) // 8], (vs, c)
+    ctx.close()
