@@ -283,55 +283,17 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
     }
 
     DG_STAMP(1);
-    // ---- phase 2.  The nearest candidate is measured first (16 bytes at a time); that sets the length to beat.  The rest
-    // are taken nearest first, LZ_POP of a mask register per pass: one whose byte at the best length so far differs
-    // cannot be longer and is dropped after that one LDS byte read -- the reference's own pruning test (:199-200), here
-    // issued for the whole batch so that the batch pays one LDS latency.  Survivors are measured in order, so that
-    // `len > best` keeps the nearest of equals ----
+    // ---- phase 2: candidates nearest first, LZ_POP of a mask register per pass, every one measured against the 16 input
+    // bytes held in registers (5 window dwords each, all reads of a pass in flight together: one LDS latency per pass);
+    // `len > best` in that order keeps the nearest of equals, like the reference's ascending scan (:196-214) ----
     uint32_t best = 2, besto = 0;
-    auto measure = [&](uint32_t qb) {
-      const uint32_t qd = qb >> 2, qs = qb & 3u;
-      const uint32_t e0 = win[(qd + 0u) * LZ_BLOCK], e1 = win[(qd + 1u) * LZ_BLOCK], e2 = win[(qd + 2u) * LZ_BLOCK],
-                     e3 = win[(qd + 3u) * LZ_BLOCK], e4 = win[(qd + 4u) * LZ_BLOCK];
-      uint32_t len = lz_common16(lz_alignbyte(e1, e0, qs), lz_alignbyte(e2, e1, qs), lz_alignbyte(e3, e2, qs), lz_alignbyte(e4, e3, qs),
-                                 T0, T1, T2, T3);
-      if (len == 16u)
-        while (len < lim && LZ_WIN8(qb + len) == LZ_WIN8(rel + len))
-          len++;
-      len = len < lim ? len : lim;
-      if (len > best)
-      {
-        best = len;
-        besto = rel - qb;
-      }
-    };
-    if (wave_any((cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) != 0))
-    {
-      int32_t r = cm[4] != 0 ? 4 : cm[3] != 0 ? 3 : cm[2] != 0 ? 2 : cm[1] != 0 ? 1 : cm[0] != 0 ? 0 : -1;
-      if (r >= 0)
-      {
-        const uint32_t m = r == 4 ? cm[4] : r == 3 ? cm[3] : r == 2 ? cm[2] : r == 1 ? cm[1] : cm[0];
-        const uint32_t bit = 31u - clz32(m);
-        const uint32_t cleared = m & ~(1u << bit);
-        cm[4] = r == 4 ? cleared : cm[4];
-        cm[3] = r == 3 ? cleared : cm[3];
-        cm[2] = r == 2 ? cleared : cm[2];
-        cm[1] = r == 1 ? cleared : cm[1];
-        cm[0] = r == 0 ? cleared : cm[0];
-        measure(4u * wd0 + 32u * (uint32_t)r + bit);
-      }
-    }
 #pragma unroll
     for (int r = 4; r >= 0; r--)
     {
       while (wave_any(cm[r] != 0 && best < lim))
       {
         uint32_t m = best < lim ? cm[r] : 0u;
-        uint32_t qb[LZ_POP], got[LZ_POP];
-        const uint32_t b0 = best;
-        // the four bytes k0..k0+3 end at byte b0 (for b0 = 2, nothing measured yet, only bytes 0..2 count): a candidate
-        // that differs there is no longer than b0; one that agrees is, up to b0 = 6, certainly longer
-        const uint32_t k0 = (b0 > 3u ? b0 : 3u) - 3u, cmpmask = b0 < 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
+        uint32_t qb[LZ_POP], e[LZ_POP][5];
         uint32_t has = 0;
 #pragma unroll
         for (uint32_t k = 0; k < LZ_POP; k++)
@@ -340,29 +302,26 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
           const uint32_t bit = 31u - clz32(m | 1u);
           m &= ~(1u << bit);
           qb[k] = 4u * wd0 + 32u * (uint32_t)r + bit; // window byte index of the candidate (a valid address also when there is none)
-          const uint32_t cb = qb[k] + k0;
-          got[k] = lz_alignbyte(win[((cb >> 2) + 1u) * LZ_BLOCK], win[(cb >> 2) * LZ_BLOCK], cb & 3u);
+          const uint32_t qd = qb[k] >> 2;
+#pragma unroll
+          for (uint32_t j = 0; j < 5; j++)
+            e[k][j] = win[(qd + j) * LZ_BLOCK];
         }
-        const uint32_t tb = rel + k0;
-        const uint32_t want = lz_alignbyte(win[((tb >> 2) + 1u) * LZ_BLOCK], win[(tb >> 2) * LZ_BLOCK], tb & 3u);
         cm[r] = best < lim ? m : cm[r];
-        uint32_t surv = 0;
 #pragma unroll
         for (uint32_t k = 0; k < LZ_POP; k++)
-          surv |= ((got[k] ^ want) & cmpmask) == 0 ? 1u << k : 0u;
-        surv &= has;
-        while (wave_any(surv != 0))
         {
-          if (surv != 0)
+          const uint32_t qs = qb[k] & 3u;
+          uint32_t len = lz_common16(lz_alignbyte(e[k][1], e[k][0], qs), lz_alignbyte(e[k][2], e[k][1], qs), lz_alignbyte(e[k][3], e[k][2], qs),
+                                     lz_alignbyte(e[k][4], e[k][3], qs), T0, T1, T2, T3);
+          if (len == 16u && ((has >> k) & 1u) != 0)
+            while (len < lim && LZ_WIN8(qb[k] + len) == LZ_WIN8(rel + len))
+              len++;
+          len = len < lim ? len : lim;
+          if (((has >> k) & 1u) != 0 && len > best)
           {
-            const uint32_t k = (uint32_t)__builtin_ctz(surv);
-            surv &= surv - 1u;
-            uint32_t q = qb[0];
-#pragma unroll
-            for (uint32_t j = 1; j < LZ_POP; j++)
-              q = k == j ? qb[j] : q;
-            if (best < lim)
-              measure(q);
+            best = len;
+            besto = rel - qb[k];
           }
         }
       }
@@ -815,25 +774,11 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
             code_sym <<= 9;
           }
         }
-        if (offset >= 4u)
+        for (uint32_t k = 0; k < length && err == OK; k++)
         {
-          // four bytes per LDS round trip: the source cannot overlap what these four positions write
-          const uint32_t *const histd = lds + LZD_OFF_HIST + tid;
-          for (uint32_t k = 0; k < length && err == OK; k += 4u)
-          {
-            const uint32_t from = (hp - offset) & (LZ_HISTORY - 1u);
-            const uint32_t v = lz_alignbyte(histd[(((from >> 2) + 1u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK], histd[(from >> 2) * LZ_BLOCK], from & 3u);
-            const uint32_t n = length - k < 4u ? length - k : 4u;
-            for (uint32_t j = 0; j < n; j++)
-              LZ_EMIT((v >> (8u * j)) & 0xFFu);
-          }
+          const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
+          LZ_EMIT(sym);
         }
-        else
-          for (uint32_t k = 0; k < length && err == OK; k++)
-          {
-            const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
-            LZ_EMIT(sym);
-          }
       }
     } while (err == OK && (ip < nbits || code_sym > 0));
 
