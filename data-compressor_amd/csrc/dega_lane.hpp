@@ -415,7 +415,7 @@ struct BacEncoder
 #else
     constexpr uint32_t NSYM = 32;
 #endif
-    constexpr uint32_t FLUSH_EVERY = 4;
+    constexpr uint32_t FLUSH_EVERY = 8; // 4 costs 2.8 % more time for the same streams; overflows (redo) stay below 1e-4 per word
 #pragma unroll
     for (uint32_t i = 0; i < NSYM; i++)
     {
@@ -897,7 +897,7 @@ struct BacDecoder
       D = (uint32_t)(da >> 32);
       ahead = (uint32_t)da;
       off += n;
-      if ((i & 3u) == 3u) // rebuild the look-ahead from the staged words
+      if ((i & 7u) == 7u) // rebuild the look-ahead from the staged words (8 symbols rarely take more than 32 bits: else redo)
       {
         bad |= (off - off_group > 32u || off > 95u) ? 1u : 0u;
         off_group = off;

@@ -230,3 +230,36 @@ def test_cli_glzmh_on_reference_test_file(lib, tmp_path):
     assert back.read_bytes() == raw
     p = run_cli([str(src), str(back), "encode", "glzmh", "#", "decode", "glzmh"])  # chained: exact bit length hand-off
     assert p.returncode == 0 and back.read_bytes() == raw
+
+
+@pytest.mark.gpu
+def test_cli_dega_with_valuesize(lib, tmp_path):
+    """`valuesize=n` through the plugin: n-bit big-endian fields in, the stream of the reference's three stages with the
+    same option out (here: the oracle's, which tests/test_valuesize.py pins to the reference), and back."""
+    from oracle import orc
+    rng = np.random.default_rng(9)
+    for vs in (12, 16, 7):
+        T = 504  # whole bytes for every one of the sizes
+        half = 1 << (vs - 1)
+        x = (np.cumsum(rng.integers(-(half // 32 + 1), half // 32 + 2, T)) + half // 2).clip(0, half - 1).astype(np.uint64)
+        bits = np.zeros(T * vs, dtype=np.uint8)
+        for k in range(vs):
+            bits[k::vs] = (x >> np.uint64(vs - 1 - k)) & np.uint64(1)
+        packed = np.packbits(bits).tobytes()
+        assert (T * vs) % 8 == 0
+        d, n = packed, T * vs
+        for name in ("diff", "seg", "bac"):
+            r, d, n = orc.stage(name, True, d, n, valuesize=vs, adaptive=1)
+            assert r == 0
+        src = tmp_path / ("in%d.bin" % vs)
+        src.write_bytes(packed)
+        enc = tmp_path / ("out%d.dega" % vs)
+        p = run_cli([str(src), str(enc), "encode", "dega", "adaptive", "valuesize=%d" % vs])
+        assert p.returncode == 0, p.stderr
+        assert enc.read_bytes() == orc.file_bytes(d, n), vs
+        back = tmp_path / ("back%d.bin" % vs)
+        p = run_cli([str(enc), str(back), "decode", "dega", "adaptive", "valuesize=%d" % vs])
+        assert p.returncode == 0, p.stderr
+        assert back.read_bytes() == packed, vs
+    p = run_cli([str(src), str(enc), "encode", "dega", "valuesize=40"])  # int32 containers end at 32
+    assert p.returncode != 0
