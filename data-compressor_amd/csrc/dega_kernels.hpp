@@ -264,15 +264,16 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
 #endif
     }
     enc.fetch_magics(tab, Mnext); // for the next code step; in flight during fill and drain
-    // ---- everything issued at the end of the previous iteration has landed by now ----------------------------------
-    wait_vector_memory();
-    DG_STAMP(5);
     // ---- phase F: the same ROWS rows for every lane ----------------------------------------------------------
     const bool room = (q.wr - q.rd) + FILL_WORDS <= RING;
     const bool fill = t < a.T && wave_all(room);
     DG_STAMP(0);
     if (fill)
     {
+      // The rows were requested right after the previous fill, one to three code steps ago; only a step that fills
+      // waits for them (a wait in every step would stop the steps in between for a DMA nobody needs yet).
+      wait_vector_memory();
+      DG_STAMP(5);
       const size_t left = a.T - t;
       uint32_t xr[ROWS];
 #pragma unroll
@@ -331,7 +332,8 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
     // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
     iter++;
-    if ((iter % ENC_DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
+    constexpr uint32_t DRAIN_EVERY = ORING >= 32 ? 2 * ENC_DRAIN_EVERY : ENC_DRAIN_EVERY; // as rarely as the column allows
+    if ((iter % DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
     {
       uint32_t base = 0; // first staged slot not yet stored
       while (wave_any(enc.staged - base >= 4u))
@@ -546,15 +548,18 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
     }
 #endif
     // ---- the DMA issued at the end of the previous step has landed: move the words to the lane's own ring slots -----
-    wait_vector_memory();
-    if (requested > 0)
+    if (wave_any(requested > 0)) // (delaying this by a step, to give the DMA more time, starves lanes: slower)
     {
+      wait_vector_memory();
+      if (requested > 0)
+      {
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++)
-        if (j < requested)
-          iring[((in_loaded + j) % DEC_IRING) * 64u] = stage_wave[j * 64u + lane];
-      in_loaded += requested;
-      requested = 0;
+        for (uint32_t j = 0; j < 4; j++)
+          if (j < requested)
+            iring[((in_loaded + j) % DEC_IRING) * 64u] = stage_wave[j * 64u + lane];
+        in_loaded += requested;
+        requested = 0;
+      }
     }
     DG_STAMP(5);
     // ---- phase S: parse what is there --------------------------------------------------------------------------------
