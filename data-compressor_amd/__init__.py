@@ -51,6 +51,12 @@ _SIGNATURES = {
     "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
     "dega_hip_decode_f32_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P]),
     "dega_hip_decode_f32_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
+    "dega_hip_worst_case_bytes64": (_Z, [_Z]),
+    "dega_hip_encode64_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
+    "dega_hip_decode64_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
+    "dega_hip_decode64_var_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dega_hip_encode64_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P]),
+    "dega_hip_decode64_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_lzmh_worst_case_bytes": (_Z, [_Z]),
     "dega_hip_lzmh_encode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P, _P]),
     "dega_hip_lzmh_decode_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P, _P]),
@@ -333,6 +339,34 @@ class Context:
         ret = library().dega_hip_decode_var_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, max_T, Cn, int(adaptive), int(valuesize),
                                                  x.ctypes.data, counts.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_decode_var_host")
+        return x, counts, err
+
+    def encode64_host(self, x_tc, valuesize, adaptive=1, cap=None):
+        """valuesize 33..64: x_tc int64 [T, C] (the low valuesize bits count)."""
+        import numpy as np
+        x_tc = np.ascontiguousarray(x_tc, dtype=np.int64)
+        T, Cn = x_tc.shape
+        if cap is None:
+            cap = library().dega_hip_worst_case_bytes64(T)
+        out = np.zeros((Cn, cap), dtype=np.uint8)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_encode64_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), int(valuesize), out.ctypes.data, cap,
+                                               bits.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_encode64_host")
+        return out, bits, err
+
+    def decode64_var_host(self, streams, bits, max_T, valuesize, adaptive=1):
+        import numpy as np
+        streams = np.ascontiguousarray(streams, dtype=np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn, cap = streams.shape
+        x = np.zeros((max_T, Cn), dtype=np.int64)
+        counts = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_decode64_var_host(self._h, streams.ctypes.data, cap, bits.ctypes.data, Cn, max_T, Cn, int(adaptive), int(valuesize),
+                                                   x.ctypes.data, counts.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_decode64_var_host")
         return x, counts, err
 
     def encode_f32_host(self, v_tc, factor=100.0, adaptive=1, cap=None, valuesize=32):

@@ -78,6 +78,12 @@ extern "C" size_t dega_hip_worst_case_bytes(size_t T)
   return ((bits + 7) / 8 + 16 + 3) & ~(size_t)3;
 }
 
+extern "C" size_t dega_hip_worst_case_bytes64(size_t T)
+{
+  const size_t bits = T * 127 * 2 + 64; // as above with the 127-bit worst-case codeword of 64-bit values
+  return ((bits + 7) / 8 + 16 + 3) & ~(size_t)3;
+}
+
 extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
 {
   if (out == nullptr)
@@ -468,6 +474,98 @@ extern "C" int dega_hip_synth_dev(dega_hip_ctx *ctx, int32_t *x_tc, size_t C, si
   return DEGA_OK;
 }
 
+// ---- valuesize 33..64: int64 containers ----------------------------------------------------------------------------------
+
+static int check_shape64(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t cap, int valuesize)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (valuesize < 33 || valuesize > 64)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "valuesize must be 33..64 for the [T][C] int64 layout", hipSuccess);
+  return check_shape(ctx, C, T, ld, cap, 32);
+}
+
+extern "C" int dega_hip_encode64_dev(dega_hip_ctx *ctx, const int64_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                     uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream)
+{
+  int ret;
+  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  EncodeArgs a;
+  a.x = reinterpret_cast<const int32_t *>(x_tc);
+  a.C = C;
+  a.T = T;
+  a.ld = ld;
+  a.out = out;
+  a.cap = cap;
+  a.out_bits = out_bits;
+  a.err = err;
+  a.div_magic = ctx->div_magic;
+  a.valuesize = (uint32_t)valuesize;
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 0, s);
+    if (adaptive)
+      hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true>), grid, dim3(BLOCK), 0, s, a);
+    else
+      hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true>), grid, dim3(BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+static int launch_decode64(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                           int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
+{
+  int ret;
+  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DecodeArgs a;
+  a.in = in;
+  a.cap = cap;
+  a.in_bits = in_bits;
+  a.C = C;
+  a.T = T;
+  a.ld = ld;
+  a.x = reinterpret_cast<int32_t *>(x_tc);
+  a.err = err;
+  a.div_magic = ctx->div_magic;
+  a.out_count = out_count;
+  a.valuesize = (uint32_t)valuesize;
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  hipStream_t s = (hipStream_t)stream;
+  {
+    LaunchTimer lt(ctx, 1, s);
+    if (adaptive)
+      hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true>), grid, dim3(BLOCK), 0, s, a);
+    else
+      hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true>), grid, dim3(BLOCK), 0, s, a);
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode64_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                     int adaptive, int valuesize, int64_t *x_tc, int32_t *err, void *stream)
+{
+  return launch_decode64(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err, stream);
+}
+
+extern "C" int dega_hip_decode64_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                         int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
+{
+  if (out_count == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  return launch_decode64(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err, stream);
+}
+
 // ---- LZMH (BASELINE config 4) ----------------------------------------------------------------------------------------
 
 extern "C" size_t dega_hip_lzmh_worst_case_bytes(size_t n)
@@ -759,6 +857,61 @@ extern "C" int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, s
   HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(out, dout.p, C * stride, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(out_len, dlen.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_encode64_host(dega_hip_ctx *ctx, const int64_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                      uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
+{
+  int ret;
+  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dx, dout, dbits, derr;
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_encode64_dev(ctx, (const int64_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_decode64_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                                          int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err)
+{
+  int ret;
+  if (out_count == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if ((ret = check_shape64(ctx, C, max_T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf din, dbits, dx, dcnt, derr;
+  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dx.alloc(max_T * ld * sizeof(int64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dcnt.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dx.p, 0, max_T * ld * sizeof(int64_t)), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_decode64_var_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, max_T, ld, adaptive, valuesize, (int64_t *)dx.p,
+                                       (uint64_t *)dcnt.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, max_T * ld * sizeof(int64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_count, dcnt.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }

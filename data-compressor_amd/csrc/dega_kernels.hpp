@@ -21,6 +21,8 @@
 
 #include <stddef.h>
 
+#include <type_traits>
+
 namespace dg
 {
 
@@ -133,17 +135,21 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
 // instantiated: <4, 8, 32, 32> -- one wave per SIMD, for batches of up to 64 Ki channels (all the waves there are) -- and
 // <8, 4, 16, 24> for larger batches: eight waves share the table, the smaller rings keep the workgroup within the CU's
 // LDS (154 KiB), and the second wave of each SIMD fills the issue slots the first leaves empty while it waits.
-template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING>
+// W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
+// writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated as <.., 4, 4, 32, 32, true>.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING,
+          bool W64 = false>
 __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a)
 {
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
-  constexpr uint32_t FILL_WORDS = (31 + 65 * ROWS) / 32; // most words a batch can add (65-bit worst-case codewords)
+  constexpr uint32_t FILL_WORDS = (31 + (W64 ? 127 : 65) * ROWS) / 32; // most words a batch can add (worst-case codewords)
+  constexpr uint32_t LDS_ROWS = W64 ? 2 * ROWS : ROWS;
   static_assert(FILL_WORDS < RING && ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
   const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
   // access with a vmcnt(0) wait):  division magics (64 KiB) | seg-bit rings | coded-word rings | input rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  __shared__ uint32_t lds[TAB_WORDS + NW * (RING + ORING + ROWS) * 64];
+  __shared__ uint32_t lds[TAB_WORDS + NW * (RING + ORING + LDS_ROWS) * 64];
   uint32_t *const tab = lds;
   uint32_t *const ring = tab + TAB_WORDS;              // seg bits waiting to be coded, per lane
   uint32_t *const oring = ring + NW * RING * 64;  // coded words waiting to be stored, per lane
@@ -163,6 +169,7 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   BitQueue q;
   q.init();
   uint32_t last = 0; // diff.c:11
+  uint64_t last64 = 0;
   int32_t lane_err = OK;
 
   // Input rows travel HBM -> LDS directly (LDS-DMA, `global_load_lds_dword`: one 256-byte row segment per wave
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   // sits right after the NEXT iteration's code step, ~6000 cycles later, when everything has long retired.  (vmcnt
   // retires in order: with register loads hipcc placed vmcnt(0) waits right behind the drain's stores -- 26 % of all
   // cycles -- and copied freshly loaded registers at the loop's back edge.)
-  uint32_t *const rows_wave = &xrows[wave * ROWS * 64]; // wave uniform
+  uint32_t *const rows_wave = &xrows[wave * LDS_ROWS * 64]; // wave uniform
   const uint32_t *const rows_col = rows_wave + lane;
   size_t t = 0; // rows consumed by fills, wave uniform; after the wait LDS holds rows [t, t + ROWS)
   const size_t t_last = a.T > 0 ? a.T - 1 : 0;
@@ -181,9 +188,25 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   // When the wave's 64 channels all exist and rows are 16-byte aligned, one LDS-DMA instruction fetches FOUR rows:
   // lanes 16r .. 16r+15 read row r's 256 bytes as 16-byte pieces, which land as row r of the [row][64] LDS image.
   const size_t c_wave0 = (size_t)blockIdx.x * (NW * 64u) + wave * 64u;
-  const bool rows_x4 = (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
+  const bool rows_x4 = !W64 && (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
   auto issue_rows = [&](size_t t0) // rows [t0, t0 + ROWS), clamped to the last row
   {
+    if constexpr (W64)
+    {
+      const int64_t *const x64 = reinterpret_cast<const int64_t *>(a.x);
+#pragma unroll
+      for (uint32_t i = 0; i < ROWS; i++)
+      {
+        const size_t row = t0 + i < a.T ? t0 + i : t_last;
+        const int32_t *const p = reinterpret_cast<const int32_t *>(x64 + row * a.ld) + 2u * (size_t)col_idx;
+        if (live)
+        {
+          dma_row_to_lds(p, rows_wave + (2u * i) * 64u, lane);          // low dword
+          dma_row_to_lds(p + 1, rows_wave + (2u * i + 1u) * 64u, lane); // high dword
+        }
+      }
+      return;
+    }
     if (rows_x4)
     {
       const uint32_t r = lane >> 4, q = lane & 15u;
@@ -275,50 +298,70 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
       wait_vector_memory();
       DG_STAMP(5);
       const size_t left = a.T - t;
-      uint32_t xr[ROWS];
-#pragma unroll
-      for (uint32_t i = 0; i < ROWS; i++)
-        xr[i] = NARROW ? rows_col[i * 64u] & vmask : rows_col[i * 64u];
-#pragma unroll
-      for (uint32_t i = 0; i < ROWS; i++)
-        DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
-      // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
-      uint32_t w[ROWS];
-      uint32_t last_try = last;
-      bool all_ok = true, any_wide = false;
-#pragma unroll
-      for (uint32_t i = 0; i < ROWS; i++)
+      if constexpr (W64)
       {
-        bool ok, wide;
-        w[i] = diff_seg_short<NARROW>(xr[i], last_try, ok, wide, vhalf);
-        all_ok = all_ok && ok;
-        any_wide = any_wide || wide;
-      }
-      if (left >= ROWS && !wave_any(any_wide && live))
-      {
-        // the steady state: a full batch of short codewords, straight-line appends
+        const uint64_t vmask64 = a.valuesize >= 64u ? ~0ull : (1ull << a.valuesize) - 1ull;
         if (live)
         {
-          last = last_try;
-          if (!all_ok && lane_err == OK)
-            lane_err = ERR_INVALID_VALUE;
 #pragma unroll
           for (uint32_t i = 0; i < ROWS; i++)
-            q.put_short<RING>(w[i], ring_col);
+            if (i < left)
+            {
+              const uint64_t u = (((uint64_t)rows_col[(2u * i + 1u) * 64u] << 32) | rows_col[(2u * i) * 64u]) & vmask64;
+              const SegWord64 sw = diff_seg64(u, last64, a.valuesize);
+              if (!sw.ok && lane_err == OK)
+                lane_err = ERR_INVALID_VALUE;
+              q.put_codeword64<RING>(sw, ring_col);
+            }
         }
       }
-      else if (live)
+      else
       {
-        // first samples of a channel, jumps, the last partial batch: the general three-piece writer, row by row
+        uint32_t xr[ROWS];
+#pragma unroll
+        for (uint32_t i = 0; i < ROWS; i++)
+          xr[i] = NARROW ? rows_col[i * 64u] & vmask : rows_col[i * 64u];
+#pragma unroll
+        for (uint32_t i = 0; i < ROWS; i++)
+          DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
+        // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
+        uint32_t w[ROWS];
+        uint32_t last_try = last;
+        bool all_ok = true, any_wide = false;
 #pragma unroll
         for (uint32_t i = 0; i < ROWS; i++)
         {
-          if (i < left)
+          bool ok, wide;
+          w[i] = diff_seg_short<NARROW>(xr[i], last_try, ok, wide, vhalf);
+          all_ok = all_ok && ok;
+          any_wide = any_wide || wide;
+        }
+        if (left >= ROWS && !wave_any(any_wide && live))
+        {
+          // the steady state: a full batch of short codewords, straight-line appends
+          if (live)
           {
-            const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
-            if (!sw.ok && lane_err == OK)
+            last = last_try;
+            if (!all_ok && lane_err == OK)
               lane_err = ERR_INVALID_VALUE;
-            q.put_codeword<RING>(sw, ring_col);
+#pragma unroll
+            for (uint32_t i = 0; i < ROWS; i++)
+              q.put_short<RING>(w[i], ring_col);
+          }
+        }
+        else if (live)
+        {
+          // first samples of a channel, jumps, the last partial batch: the general three-piece writer, row by row
+#pragma unroll
+          for (uint32_t i = 0; i < ROWS; i++)
+          {
+            if (i < left)
+            {
+              const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
+              if (!sw.ok && lane_err == OK)
+                lane_err = ERR_INVALID_VALUE;
+              q.put_codeword<RING>(sw, ring_col);
+            }
           }
         }
       }
@@ -412,11 +455,13 @@ struct DecodeArgs
 
 // NW = waves per workgroup: 4 (one per SIMD) for batches of up to 64 Ki channels, 8 for larger ones -- two waves per SIMD
 // fill the issue slots a lone wave leaves empty while it waits on LDS or memory (the LDS budget allows it: 138 KiB)
-template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES>
+// W64: valuesize 33..64 -- a.x is int64 [T][ld]; the parser is SegParser64 (no short-codeword passes), samples take two
+// LDS slots.  Instantiated with NW = 4.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, bool W64 = false>
 __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + DEC_SRING + 1) * 64; // + a spare sample slot
+  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + (W64 ? 2 : 1) * (DEC_SRING + 1)) * 64; // + a spare sample slot
   __shared__ uint32_t lds[TAB_WORDS + NW * PER_WAVE];
   uint32_t *const tab = lds;
   load_div_table<ADAPTIVE>(tab, a.div_magic);
@@ -429,6 +474,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
   uint32_t *const iring = wave_lds + lane;                               // staged stream words
   uint32_t *const stage_wave = wave_lds + DEC_IRING * 64;                // DMA landing rows (wave uniform)
   uint32_t *const sring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded samples
+  uint32_t *const sring_hi = sring + (DEC_SRING + 1) * 64;               // their high dwords (W64 only)
 
   const uint32_t cap_words = (uint32_t)(a.cap / 4);
   const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
@@ -441,8 +487,8 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
   in.nbits = nbits;
   BacDecoder<ADAPTIVE> dec;
   dec.init();
-  SegParser sp;
-  sp.init(NARROW ? a.valuesize : 32u);
+  typename std::conditional<W64, SegParser64, SegParser>::type sp;
+  sp.init(NARROW || W64 ? a.valuesize : 32u);
   uint32_t seg_bits = 0; // seg bits decoded so far
 
   uint32_t in_loaded = 0;    // stream words staged so far (a multiple of 4 until the end)
@@ -568,28 +614,31 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       //     to a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data and the window
       //     up to 64 bits, so the first pass takes up to 6 -- which is all there is for nearly every wave -- and the rare
       //     follow-up passes 2 each
-      auto take = [&]() {
-        uint32_t sample;
-        const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
-        const bool took = sp.take_short<NARROW>(allowed, sample);
-        sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
-        t_lane += took ? 1u : 0u;
-        return took;
-      };
-      bool more = true;
-#pragma unroll
-      for (uint32_t k = 0; k < 6; k++)
-        more = take();
-      DG_STAMP(2);
-      while (wave_any(more))
+      if constexpr (!W64)
       {
-        more = take();
-        more = take();
+        auto take = [&]() {
+          uint32_t sample;
+          const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
+          const bool took = sp.template take_short<NARROW>(allowed, sample);
+          sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
+          t_lane += took ? 1u : 0u;
+          return took;
+        };
+        bool more = true;
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++)
+          more = take();
         DG_STAMP(2);
+        while (wave_any(more))
+        {
+          more = take();
+          more = take();
+          DG_STAMP(2);
+        }
       }
       // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;
       //     entered only by lanes that cannot simply wait for more bits
-      bool stalled = lane_final || t_lane - rows_stored >= DEC_SRING || !(bac_done || sp.cnt >= 32u || (sp.need | sp.zeros) != 0u);
+      bool stalled = lane_final || t_lane - rows_stored >= DEC_SRING || !(bac_done || sp.cnt >= 32u || sp.pending());
       while (wave_any(!stalled))
       {
         if (!stalled)
@@ -598,8 +647,12 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
             stalled = true; // sample ring full until rows are written
           else
           {
-            uint32_t sample = 0;
-            const int32_t r = sp.next<NARROW>(bac_done, sample);
+            typename std::conditional<W64, uint64_t, uint32_t>::type sample = 0;
+            int32_t r;
+            if constexpr (W64)
+              r = sp.next(bac_done, sample);
+            else
+              r = sp.template next<NARROW>(bac_done, sample);
             if (r == 1)
             {
               if (t_lane >= a.T)
@@ -611,7 +664,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
               }
               else
               {
-                sring[(t_lane % DEC_SRING) * 64u] = sample;
+                sring[(t_lane % DEC_SRING) * 64u] = (uint32_t)sample;
+                if constexpr (W64)
+                  sring_hi[(t_lane % DEC_SRING) * 64u] = (uint32_t)((uint64_t)sample >> 32);
                 t_lane++;
               }
             }
@@ -642,10 +697,14 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
     // every lane has is stored.  (With a reported count, rows past the longest channel of the wave are not written.)
     for (;;)
     {
-      uint32_t cand[4];
+      uint32_t cand[4], cand_hi[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++)
+      {
         cand[k] = sring[((rows_stored + k) % DEC_SRING) * 64u];
+        if constexpr (W64)
+          cand_hi[k] = sring_hi[((rows_stored + k) % DEC_SRING) * 64u];
+      }
       uint32_t wrote = 0;
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++)
@@ -653,7 +712,12 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         const size_t row = rows_stored + k;
         if (wrote == k && row < a.T && wave_all(lane_final || t_lane > row) && (a.out_count == nullptr || wave_any(t_lane > row)))
         {
-          if (live)
+          if constexpr (W64)
+          {
+            if (live)
+              reinterpret_cast<int64_t *>(a.x)[row * a.ld + c] = t_lane > row ? (int64_t)(((uint64_t)cand_hi[k] << 32) | cand[k]) : 0;
+          }
+          else if (live)
             a.x[row * a.ld + c] = t_lane > row ? (int32_t)cand[k] : 0;
           wrote = k + 1;
         }

@@ -595,6 +595,31 @@ DG_DEV uint32_t diff_seg_short(uint32_t u, uint32_t &last, bool &ok, bool &wide,
   return w;
 }
 
+// ---- valuesize 33..64: samples in 64-bit containers -------------------------------------------------------------------
+// Same functions of the difference, 64 bits wide, in the reference's own 64-bit arithmetic: for valuesize 64 the range
+// check is skipped (diff.c:17), the difference wraps, and for |v| = 2^63 so does the code number (-2v = 0 in io_uint_t,
+// seg.c:25-28): that difference is coded like 0 -- a loss the reference has and this reproduces.  w < 2^64, codeword
+// 2p + 1 <= 127 bits.
+struct SegWord64
+{
+  uint64_t w; // code_number + 1
+  uint32_t p; // prefix length, 0..63
+  bool ok;
+};
+
+DG_DEV SegWord64 diff_seg64(uint64_t u, uint64_t &last, uint32_t valuesize)
+{
+  SegWord64 r;
+  const uint64_t d = u - last; // u, last < 2^valuesize, zero extended (diff.c:15)
+  const uint64_t half = 1ull << (valuesize - 1u);
+  r.ok = valuesize >= 64u || d + half < 2ull * half; // valuesize <= 63 where checked: 2 * half does not wrap
+  last = u;
+  const int64_t v = (int64_t)d;
+  r.w = v > 0 ? 2ull * (uint64_t)v : 2ull * (0ull - (uint64_t)v) + 1ull; // (2v - 1) + 1  |  -2v + 1, mod 2^64
+  r.p = 63u - (uint32_t)__builtin_clzll(r.w);                            // w >= 1
+  return r;
+}
+
 // Per-lane bit queue feeding the coder: bits are appended MSB first, whole 32-bit words go to the lane's column of an
 // LDS ring (slot-major: ring[slot * 64 + lane], so a wave's access is always conflict free).
 struct BitQueue
@@ -656,6 +681,25 @@ struct BitQueue
       else
         put<RING>(s.w_lo, s.p + 1u, ring_col); // delimiting one + residual (seg.c:19)
     }
+  }
+
+  template <uint32_t RING>
+  DG_DEV void put_codeword64(const SegWord64 &s, uint32_t *ring_col) // p zeros, then w in p + 1 bits, in pieces of <= 32
+  {
+    uint32_t z = s.p;
+    while (z > 0)
+    {
+      const uint32_t k = z < 32u ? z : 32u;
+      put<RING>(0u, k, ring_col);
+      z -= k;
+    }
+    uint32_t n = s.p + 1u; // bits of w to write, most significant first (w < 2^n)
+    if (n > 32u)
+    {
+      put<RING>((uint32_t)(s.w >> 32), n - 32u, ring_col);
+      n = 32u;
+    }
+    put<RING>((uint32_t)s.w, n, ring_col);
   }
 };
 
@@ -952,6 +996,11 @@ struct SegParser
     return cnt <= 32u;
   }
 
+  DG_DEV bool pending() const // inside a codeword
+  {
+    return (need | zeros) != 0u;
+  }
+
   DG_DEV void push(uint32_t bits, uint32_t n) // n <= 32 bits, right aligned in `bits`; cnt + n <= 64
   {
     if (n > 0)
@@ -1051,6 +1100,107 @@ struct SegParser
     emit<NARROW>(win >> (64u - need), sample); // (1 << prefix) | residual = code_number + 1 (seg.c:64-66)
     drop(need);
     need = 0;
+    return 1;
+  }
+};
+
+// valuesize 33..64: the same parser over 64-bit values.  Codewords reach 127 bits here (the reference caps the prefix
+// at min(valuesize + 1, 64) zeros, seg.c:74, so |v| = 2^63 cannot be decoded by it either), more than the window holds:
+// the prefix is counted across refills, the delimiting one is taken on its own and the residual is gathered in as many
+// pieces as it takes.  No short-codeword fast path: these sizes are for completeness, not for speed.
+struct SegParser64
+{
+  uint64_t win;
+  uint32_t cnt;
+  uint32_t zeros;      // zero-prefix bits of the current codeword counted so far
+  uint32_t resid_left; // residual bits still to come (valid while in_resid)
+  bool in_resid;       // the delimiting one has been taken
+  uint64_t resid;
+  uint64_t last;       // diff.c:27
+  uint32_t cap, vshift;
+  uint64_t vmask;
+
+  DG_DEV void init(uint32_t valuesize)
+  {
+    win = 0;
+    cnt = 0;
+    zeros = 0;
+    resid_left = 0;
+    in_resid = false;
+    resid = 0;
+    last = 0;
+    cap = valuesize + 1u > 64u ? 64u : valuesize + 1u;
+    vshift = 64u - valuesize;
+    vmask = valuesize >= 64u ? ~0ull : (1ull << valuesize) - 1ull;
+  }
+
+  DG_DEV bool has_room() const
+  {
+    return cnt <= 32u;
+  }
+
+  DG_DEV bool pending() const
+  {
+    return in_resid || zeros != 0u;
+  }
+
+  DG_DEV void push(uint32_t bits, uint32_t n)
+  {
+    if (n > 0)
+    {
+      win |= (uint64_t)bits << (64u - n) >> cnt;
+      cnt += n;
+    }
+  }
+
+  DG_DEV void drop(uint32_t n)
+  {
+    win = n >= 64u ? 0 : win << n;
+    cnt -= n;
+  }
+
+  // 1 = a sample, 0 = more bits needed, 2 = clean end of stream, negative = error (as SegParser::next)
+  DG_DEV int32_t next(bool final, uint64_t &sample)
+  {
+    if (!in_resid)
+    {
+      const uint32_t lz = win ? (uint32_t)__builtin_clzll(win) : 64u;
+      const uint32_t z = lz < cnt ? lz : cnt;
+      zeros += z;
+      if (zeros >= cap)
+        return ERR_INVALID_FORMAT; // seg.c:55-56
+      drop(z);
+      if (cnt == 0)
+        return final ? 2 : 0; // EOF inside the prefix, or nothing left: padding / clean end (seg.c:58-62)
+      drop(1); // the delimiting one
+      in_resid = true;
+      resid_left = zeros;
+      resid = 0;
+    }
+    if (resid_left > 0)
+    {
+      if (cnt == 0)
+      {
+        if (!final)
+          return 0;
+        return resid_left == zeros ? 2 : ERR_LIBRARY_CALL; // EOF right after the delimiter is padding; later a short read
+      }
+      const uint32_t k = cnt < resid_left ? cnt : resid_left; // 1..63 (zeros < cap <= 64)
+      resid = (resid << k) | (win >> (64u - k));
+      drop(k);
+      resid_left -= k;
+      if (resid_left > 0)
+        return final ? ERR_LIBRARY_CALL : 0;
+    }
+    const uint64_t w = (1ull << zeros) | resid; // code_number + 1 (seg.c:64-66); zeros <= 63
+    const uint64_t mag = w >> 1;
+    uint64_t d = (w & 1ull) ? 0ull - mag : mag; // seg.c:76-78
+    if (vshift != 0)
+      d = (uint64_t)((int64_t)(d << vshift) >> vshift); // decode diff reads it back as valuesize bits (diff.c:31-32)
+    last += d;
+    sample = last & vmask;
+    zeros = 0;
+    in_resid = false;
     return 1;
   }
 };

@@ -153,9 +153,9 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   const size_t in_vs = is_float ? 32 : vs; /* normalize always reads 32-bit floats (normalize.c:15) */
   io_int_t ret;
 
-  if (vs < 1 || vs > 32)
+  if (vs < 1 || vs > 64 || (is_float && vs > 32))
   {
-    LOG_TO(log, "dega: valuesize 1..32 is supported on the GPU path (int32 sample containers)\n");
+    LOG_TO(log, "dega: valuesize 1..64 is supported on the GPU path (1..32 with the float entry)\n");
     return ERROR_INVALID_VALUE;
   }
   if ((ret = get_context(log, &ctx)) != NO_ERROR)
@@ -175,11 +175,11 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
     goto done;
   }
   T = (size_t)(nbits / in_vs) / C;
-  cap = dega_hip_worst_case_bytes(T);
+  cap = vs > 32 ? dega_hip_worst_case_bytes64(T) : dega_hip_worst_case_bytes(T);
   streams = (uint8_t *)malloc(C * cap);
   bits = (uint64_t *)calloc(C, sizeof(uint64_t));
   err = (int32_t *)calloc(C, sizeof(int32_t));
-  x = (int32_t *)malloc((T * C + 1) * sizeof(int32_t));
+  x = (int32_t *)malloc((T * C + 1) * (vs > 32 ? sizeof(int64_t) : sizeof(int32_t)));
   if (streams == NULL || bits == NULL || err == NULL || x == NULL)
   {
     ret = ERROR_MEMORY;
@@ -190,6 +190,22 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
     memcpy(x, raw.p, T * C * 4); /* raw native-endian float32, as `decode csv` writes them (csv.c:13-44) */
     ret = dega_hip_encode_f32_host(ctx, (const float *)(const void *)x, C, T, C, options->normalization_factor, options->adaptive, (int)vs,
                                    streams, cap, bits, err);
+  }
+  else if (vs > 32) /* 64-bit containers */
+  {
+    int64_t *const x64 = (int64_t *)(void *)x;
+    for (t = 0; t < T * C; t++) /* valuesize-bit values, MSB first, zero extended */
+    {
+      uint64_t v = 0;
+      size_t k;
+      for (k = 0; k < vs; k++)
+      {
+        const uint64_t at = (uint64_t)t * vs + k;
+        v = (v << 1) | ((raw.p[at >> 3] >> (7 - (at & 7))) & 1u);
+      }
+      x64[t] = (int64_t)v;
+    }
+    ret = dega_hip_encode64_host(ctx, x64, C, T, C, options->adaptive, (int)vs, streams, cap, bits, err);
   }
   else
   {
@@ -279,9 +295,9 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   int known_T = 0;
   io_int_t ret;
 
-  if (vs < 1 || vs > 32)
+  if (vs < 1 || vs > 64 || (is_float && vs > 32))
   {
-    LOG_TO(log, "dega: valuesize 1..32 is supported on the GPU path (int32 sample containers)\n");
+    LOG_TO(log, "dega: valuesize 1..64 is supported on the GPU path (1..32 with the float entry)\n");
     return ERROR_INVALID_VALUE;
   }
   if ((ret = get_context(log, &ctx)) != NO_ERROR)
@@ -361,12 +377,20 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   for (;;)
   {
     free(x);
-    if ((x = (int32_t *)malloc((T * C + 1) * sizeof(int32_t))) == NULL)
+    if ((x = (int32_t *)malloc((T * C + 1) * (vs > 32 ? sizeof(int64_t) : sizeof(int32_t)))) == NULL)
     {
       ret = ERROR_MEMORY;
       goto done;
     }
-    if (is_float)
+    if (vs > 32) /* 64-bit containers: the variable-length entry serves both cases */
+    {
+      ret = dega_hip_decode64_var_host(ctx, streams, cap, bits, C, T, C, options->adaptive, (int)vs, (int64_t *)(void *)x, counts, err);
+      if (ret == DEGA_OK && known_T)
+        for (c = 0; c < C; c++)
+          if (err[c] == NO_ERROR && counts[c] != T)
+            err[c] = ERROR_INVALID_FORMAT;
+    }
+    else if (is_float)
       ret = known_T ? dega_hip_decode_f32_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, (int)vs, (float *)(void *)x, err)
                     : dega_hip_decode_f32_var_host(ctx, streams, cap, bits, C, T, C, options->normalization_factor, options->adaptive, (int)vs, (float *)(void *)x, counts, err);
     else
@@ -397,7 +421,7 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
     }
     else
     {
-      const io_uint_t v = (uint32_t)x[t];
+      const io_uint_t v = vs > 32 ? (io_uint_t)((const int64_t *)(const void *)x)[t] : (io_uint_t)(uint32_t)x[t];
       if (WriteSingleValueToBitFileBuffer(out, &v, vs) != (io_int_t)vs)
         ret = ERROR_LIBRARY_CALL;
     }

@@ -16,7 +16,7 @@
  * is shown in INTEGRATION.md and implemented in data-compressor_amd/host/.
  *
  * Per channel the produced bytes and the exact bit length equal what the reference's chain
- *     encode diff # encode seg # encode bac [adaptive]        (valuesize 1..32)
+ *     encode diff # encode seg # encode bac [adaptive]        (valuesize 1..64)
  * produces for that channel alone; errors are per channel and use the reference's codes (common/inc/err_codes.h:8-32).
  *
  * Layouts
@@ -63,8 +63,7 @@ size_t dega_hip_worst_case_bytes(size_t T);
 /* valuesize: 1..32, the `valuesize` option of the three stages (DCLib/src/enc_dec.c:72).  A sample is the low valuesize
    bits of its int32 container, read unsigned as diff.c:15 does; bits above are ignored on encode and zero on decode.
    The difference must fit valuesize bits signed, else that channel reports ERROR_INVALID_VALUE (diff.c:17-18); the
-   decoder caps a codeword's zero prefix at valuesize + 1 (seg.c:55-56,74).  33..64 would need 64-bit containers: not
-   carried by this layout.  adaptive: 0 = `bac`, 1 = `bac adaptive`. */
+   decoder caps a codeword's zero prefix at valuesize + 1 (seg.c:55-56,74).  33..64: the *64 entry points below.  adaptive: 0 = `bac`, 1 = `bac adaptive`. */
 int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                         uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
 /* in_bits[c] is the exact bit length, or 8*bytes when the stream comes from a zero-padded file.  Decodes exactly T
@@ -77,6 +76,23 @@ int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const 
    out_count[c]; a channel holding more than max_T samples gets DEGA_ERROR_MEMORY (call again with more room). */
 int dega_hip_decode_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
                             int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream);
+
+/* ---- valuesize 33..64: the same path with 64-bit containers -------------------------------------------------------- */
+/* x_tc is int64 [T][ld]; a sample is the low valuesize bits, unsigned; for valuesize 64 the difference wraps and is not
+   range checked (diff.c:17); a difference of magnitude 2^63 is coded like 0 (the reference's code number wraps, seg.c:25-28)
+   -- the one lossy case, reproduced.  The decoder caps the zero prefix at min(valuesize + 1, 64) (seg.c:74).
+   Slabs: dega_hip_worst_case_bytes64. */
+size_t dega_hip_worst_case_bytes64(size_t T);
+int dega_hip_encode64_dev(dega_hip_ctx *ctx, const int64_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                          uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
+int dega_hip_decode64_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                          int adaptive, int valuesize, int64_t *x_tc, int32_t *err, void *stream);
+int dega_hip_decode64_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                              int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err, void *stream);
+int dega_hip_encode64_host(dega_hip_ctx *ctx, const int64_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                           uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
+int dega_hip_decode64_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
+                               int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err);
 
 /* ---- float entry / exit (normalize.c), device pointers ----------------------------------------------------------- */
 /* v: float32 [T][ld] -> x: int32 [T][ld]; err[c] = DEGA_ERROR_INVALID_VALUE if any sample of channel c fails the range check. */

@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs):
   kats.json            known-answer vectors re-generated through the reference library
   channels.npz         small int32 channel batches [T][C] + the reference's per-channel DEGA streams
   floats.npz           float32 edge cases + the reference's normalize / denormalize results
+  valuesizes64.npz     the same for valuesize 33..64 (uint64 samples), including differences the decoder cannot take back
   valuesizes.npz       channel batches for valuesize 1..31 (unsigned valuesize-bit samples) + the reference's streams of
                        `encode diff valuesize=n # encode seg valuesize=n # encode bac [adaptive]`, error channels included
   lzmh.json / lzmh.npz the reference's `encode lzmh` of the test file (size, bits, sha256) and of small byte strings
@@ -250,6 +251,67 @@ def valuesizes():
     print("valuesizes:", {k[:-7]: int((v != 0).sum()) for k, v in out.items() if k.endswith(".ad.err")}, "(channels in error)")
 
 
+def valuesizes64():
+    rng = np.random.default_rng(64)
+    out = {}
+    for vs in (33, 40, 48, 63, 64):
+        T, Cn = 80, 10
+        top = (1 << vs) - 1
+        x = np.zeros((T, Cn), dtype=np.uint64)
+        for c in range(Cn):
+            kind = c % 5
+            if kind == 0:
+                col = [int(v) for v in np.clip(np.cumsum(rng.integers(-1000, 1001, T)) + 10**6, 0, None)]
+            elif kind == 1:
+                col = [int(rng.integers(0, 2**62)) * 4 % (top + 1) for _ in range(T)]  # jumps: range errors below 64 bits
+            elif kind == 2:
+                col, cur = [], top // 4
+                for _ in range(T):
+                    cur = min(max(cur + int(rng.integers(-(2 ** (vs - 3)), 2 ** (vs - 3))), 0), top // 2)
+                    col.append(cur)
+            elif kind == 3:
+                col = [top // 3] * T
+            elif vs == 64 and c == 9:
+                col = [0, 1 << 63, (1 << 63) + 5, 5, 0] * (T // 5)  # a difference of magnitude 2^63: encodes, does not decode (seg.c:74)
+            else:
+                col = [0, top // 2, 0, 1, top // 2 - 1] * (T // 5)
+            x[:, c] = np.array(col, dtype=np.uint64)
+        out["vs%d.x" % vs] = x
+        for ad in (1, 0):
+            streams, bits, errs, decs = [], [], [], []
+            decoded = np.zeros((T, Cn), dtype=np.uint64)
+            opt = " valuesize=%d" % vs
+            for c in range(Cn):
+                data, n = pack_be(x[:, c], vs)
+                ret, b, nb, _ = orc.ref_run_chain(data, n, ["encode diff" + opt, "encode seg" + opt, "encode bac adaptive" if ad else "encode bac"])
+                streams.append(b if ret == 0 else b"")
+                bits.append(nb if ret == 0 else 0)
+                errs.append(ret)
+                rd = 0
+                if ret == 0:  # what the reference's own decoder makes of it: the input, except after a difference of 2^63
+                    rd, d, dn, _ = orc.ref_run_chain(b, nb, ["decode bac adaptive" if ad else "decode bac", "decode seg" + opt, "decode diff" + opt])
+                    if rd == 0:
+                        assert dn == n, (vs, c)
+                        dbits = np.unpackbits(np.frombuffer(d, dtype=np.uint8))[:dn].reshape(-1, vs).astype(np.uint64)
+                        for k in range(vs):
+                            decoded[:, c] |= dbits[:, k] << np.uint64(vs - 1 - k)
+                        assert (d[: (dn + 7) // 8] == data) or (vs == 64 and c == 9), (vs, c)
+                decs.append(rd)
+            cap = max(1, max(len(s_) for s_ in streams))
+            arr = np.zeros((Cn, cap), dtype=np.uint8)
+            for c, s_ in enumerate(streams):
+                arr[c, : len(s_)] = np.frombuffer(s_, dtype=np.uint8)
+            tag = "vs%d.%s" % (vs, "ad" if ad else "st")
+            out[tag + ".stream"] = arr
+            out[tag + ".bits"] = np.array(bits, dtype=np.uint64)
+            out[tag + ".err"] = np.array(errs, dtype=np.int32)
+            out[tag + ".decerr"] = np.array(decs, dtype=np.int32)
+            out[tag + ".dec"] = decoded
+    np.savez_compressed(os.path.join(HERE, "valuesizes64.npz"), **out)
+    print("valuesizes64:", {k[:-7]: int((v != 0).sum()) for k, v in out.items() if k.endswith(".ad.err")}, "(channels in error)",
+          "lossy columns:", [k for k, v in out.items() if k.endswith(".ad.dec") and (v != out[k[:-7] + ".x"]).any()])
+
+
 def lzmh_inputs():
     """Deterministic byte strings for the LZMH fixtures (name -> bytes)."""
     rng = np.random.default_rng(11)
@@ -303,8 +365,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if only == ["valuesizes"]:
         valuesizes()
+        valuesizes64()
         sys.exit(0)
     channels()
     floats()
     valuesizes()
+    valuesizes64()
     lzmh()

@@ -250,3 +250,28 @@ extern "C" __attribute__((visibility("default"))) int sim_decode_wide(const uint
     sim::launch(dega_decode_kernel<false, false, 8>, grid, dim3(512), a);
   return 0;
 }
+
+// valuesize 33..64: int64 containers
+extern "C" __attribute__((visibility("default"))) int sim_encode64(const int64_t *x, size_t C, size_t T, size_t ld, int adaptive, int valuesize, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
+{
+  static const std::vector<uint32_t> tab = make_table();
+  EncodeArgs a{reinterpret_cast<const int32_t *>(x), C, T, ld, out, cap, bits, err, tab.data(), (uint32_t)valuesize};
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  if (adaptive)
+    sim::launch(dega_encode_kernel<true, false, 4, 4, 32, 32, true>, grid, dim3(BLOCK), a);
+  else
+    sim::launch(dega_encode_kernel<false, false, 4, 4, 32, 32, true>, grid, dim3(BLOCK), a);
+  return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int sim_decode64(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int valuesize, int64_t *x, uint64_t *counts, int32_t *err)
+{
+  static const std::vector<uint32_t> tab = make_table();
+  DecodeArgs a{in, cap, in_bits, C, T, ld, reinterpret_cast<int32_t *>(x), err, tab.data(), counts, (uint32_t)valuesize};
+  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  if (adaptive)
+    sim::launch(dega_decode_kernel<true, false, 4, true>, grid, dim3(BLOCK), a);
+  else
+    sim::launch(dega_decode_kernel<false, false, 4, true>, grid, dim3(BLOCK), a);
+  return 0;
+}

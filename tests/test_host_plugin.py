@@ -238,10 +238,11 @@ def test_cli_dega_with_valuesize(lib, tmp_path):
     same option out (here: the oracle's, which tests/test_valuesize.py pins to the reference), and back."""
     from oracle import orc
     rng = np.random.default_rng(9)
-    for vs in (12, 16, 7):
+    for vs in (12, 16, 7, 40, 64):  # 1..32 in int32 containers, 33..64 in int64 ones
         T = 504  # whole bytes for every one of the sizes
         half = 1 << (vs - 1)
-        x = (np.cumsum(rng.integers(-(half // 32 + 1), half // 32 + 2, T)) + half // 2).clip(0, half - 1).astype(np.uint64)
+        step = min(half // 32, 1 << 40)
+        x = (np.cumsum(rng.integers(-(step + 1), step + 2, T)) + half // 2).clip(0, half - 1).astype(np.uint64)
         bits = np.zeros(T * vs, dtype=np.uint8)
         for k in range(vs):
             bits[k::vs] = (x >> np.uint64(vs - 1 - k)) & np.uint64(1)
@@ -261,5 +262,5 @@ def test_cli_dega_with_valuesize(lib, tmp_path):
         p = run_cli([str(enc), str(back), "decode", "dega", "adaptive", "valuesize=%d" % vs])
         assert p.returncode == 0, p.stderr
         assert back.read_bytes() == packed, vs
-    p = run_cli([str(src), str(enc), "encode", "dega", "valuesize=40"])  # int32 containers end at 32
+    p = run_cli([str(src), str(enc), "encode", "fdega", "valuesize=40"])  # the float entry ends at 32 (normalize on int32)
     assert p.returncode != 0

@@ -284,3 +284,111 @@ def test_gpu_valuesize_large_batch_wide_workgroups():
             if r == 0:
                 assert int(bb[c]) == n and ob[c, : (n + 7) // 8].tobytes() == d[: (n + 7) // 8], (vs, c)
     ctx.close()
+
+
+# ---- valuesize 33..64: 64-bit containers -----------------------------------------------------------------------------------
+SIZES64 = (33, 40, 48, 63, 64)
+
+
+@pytest.fixture(scope="module")
+def gold64():
+    return np.load(os.path.join(GOLDEN, "valuesizes64.npz"))
+
+
+def unpack_be64(data, nbits, vs):
+    bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))[:nbits].reshape(-1, vs).astype(np.uint64)
+    out = np.zeros(bits.shape[0], dtype=np.uint64)
+    for k in range(vs):
+        out |= bits[:, k] << np.uint64(vs - 1 - k)
+    return out
+
+
+def check_streams64(gold64, vs, tag, out, bits, err):
+    ge, gb, gs = gold64["vs%d.%s.err" % (vs, tag)], gold64["vs%d.%s.bits" % (vs, tag)], gold64["vs%d.%s.stream" % (vs, tag)]
+    assert (np.asarray(err) == ge).all(), (vs, tag)
+    for c in np.nonzero(ge == 0)[0]:
+        nb = int(gb[c])
+        assert int(bits[c]) == nb and bytes(out[c][: (nb + 7) // 8]) == gs[c, : (nb + 7) // 8].tobytes(), (vs, tag, int(c))
+
+
+def test_oracle_stages_with_valuesize_above_32(gold64):
+    lossy = 0
+    for vs in SIZES64:
+        x = gold64["vs%d.x" % vs]
+        for ad, tag in ((1, "ad"), (0, "st")):
+            outs, bits, errs = [], [], []
+            for c in range(x.shape[1]):
+                data, n = pack_be(x[:, c], vs)
+                r = 0
+                for name in ("diff", "seg", "bac"):
+                    r, data, n = orc.stage(name, True, data, n, valuesize=vs, adaptive=ad)
+                    if r != 0:
+                        break
+                outs.append(data if r == 0 else b"")
+                bits.append(n if r == 0 else 0)
+                errs.append(r)
+                if r == 0:
+                    d, dn, r2 = data, n, 0
+                    for name in ("bac", "seg", "diff"):
+                        r2, d, dn = orc.stage(name, False, d, dn, valuesize=vs, adaptive=ad)
+                        assert r2 == 0
+                    back = unpack_be64(d, dn, vs)
+                    assert (back == gold64["vs%d.%s.dec" % (vs, tag)][:, c]).all()
+                    lossy += int((back != x[:, c]).any())
+            check_streams64(gold64, vs, tag, outs, bits, errs)
+    assert lossy == 2  # valuesize 64, both models: the difference of magnitude 2^63 is coded like 0 (seg.c:25-28 wraps)
+
+
+def _sim64(sim):
+    sim.sim_encode64.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    sim.sim_decode64.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    return sim
+
+
+def _roundtrip64(gold64, sizes, encode, decode_var):
+    for vs in sizes:
+        x = gold64["vs%d.x" % vs]
+        T, Cn = x.shape
+        xin = np.ascontiguousarray(x.view(np.int64))
+        for ad, tag in ((1, "ad"), (0, "st")):
+            out, bits, err = encode(xin, vs, ad)
+            check_streams64(gold64, vs, tag, out, bits, err)
+            ok = err == 0
+            y, counts, derr = decode_var(out, np.where(ok, bits, 0).astype(np.uint64), T + 3, vs, ad)
+            want = gold64["vs%d.%s.dec" % (vs, tag)]
+            assert (derr[ok] == gold64["vs%d.%s.decerr" % (vs, tag)][ok]).all(), (vs, tag)
+            assert (counts[ok] == T).all() and (y[:T].view(np.uint64)[:, ok] == want[:, ok]).all(), (vs, tag)
+
+
+def test_kernel_logic_with_valuesize_above_32(sim, gold64):
+    _sim64(sim)
+
+    def encode(xin, vs, ad):
+        T, Cn = xin.shape
+        cap = 4 * ((T * (2 * vs + 3) // 4 + 64) // 4 + 4)
+        out = np.zeros((Cn, cap), dtype=np.uint8)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        sim.sim_encode64(xin.ctypes.data, Cn, T, Cn, ad, vs, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+        return out, bits, err
+
+    def decode_var(out, bits, room, vs, ad):
+        Cn, cap = out.shape
+        y = np.zeros((room, Cn), dtype=np.int64)
+        counts = np.zeros(Cn, dtype=np.uint64)
+        derr = np.zeros(Cn, dtype=np.int32)
+        sim.sim_decode64(out.ctypes.data, cap, bits.ctypes.data, Cn, room, Cn, ad, vs, y.ctypes.data, counts.ctypes.data, derr.ctypes.data)
+        return y, counts, derr
+    _roundtrip64(gold64, (40, 64), encode, decode_var)
+
+
+@pytest.mark.gpu
+def test_gpu_valuesize_above_32(gold64):
+    from __graft_entry__ import load_package
+    dca = load_package()
+    ctx = dca.Context(0)
+    _roundtrip64(gold64, SIZES64, lambda xin, vs, ad: ctx.encode64_host(xin, vs, adaptive=ad),
+                 lambda out, bits, room, vs, ad: ctx.decode64_var_host(out, bits, room, vs, adaptive=ad))
+    with pytest.raises(dca.DegaError):
+        ctx.encode64_host(np.zeros((4, 4), dtype=np.int64), 32)  # 1..32 live in the int32 entry points
+    ctx.close()
