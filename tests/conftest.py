@@ -22,3 +22,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_artefacts():
+    """Built files are not in the history (they travel with the working tree).  On a tree that lacks them -- a fresh
+    checkout -- compile what the tests load: the HIP library (hipcc cross-compiles gfx950 without a GPU) and the checker."""
+    import subprocess
+    pkg = os.path.join(ROOT, "data-compressor_amd")
+    if not os.path.exists(os.path.join(pkg, "libdega_hip.so")) and os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-s", "-C", os.path.join(pkg, "csrc")], check=True)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+    yield
