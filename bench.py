@@ -101,11 +101,15 @@ def main():
                     help="channels of the host-pointer (PCIe-inclusive) measurement after the timed region (0 = skip)")
     ap.add_argument("--lzmh-input", choices=("ascii", "raw"), default="ascii",
                     help="lzmh workload: the channels as ASCII '%%d.%%02d\\n' lines (the codec's domain) or as raw big-endian int32 bytes")
-    ap.add_argument("--workload", choices=("dega", "lzmh"), default="dega",
-                    help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH")
+    ap.add_argument("--workload", choices=("dega", "lzmh", "roundtrip"), default="dega",
+                    help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH; "
+                         "roundtrip = one GPU's share of configs[4]: --channels streamed in batches of --batch-channels, encode + decode + compare")
+    ap.add_argument("--batch-channels", type=int, default=131072, help="roundtrip workload: channels per batch (x + slabs + decoded samples must fit HBM)")
     args = ap.parse_args()
     if args.workload == "lzmh":
         return main_lzmh(args)
+    if args.workload == "roundtrip":
+        return main_roundtrip(args)
 
     import numpy as np
     import torch
@@ -242,6 +246,98 @@ def main():
     if pool is not None:
         pool.close()
         pool.join()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def main_roundtrip(args):
+    """One GPU's share of BASELINE configs[4] (8 Mi channels x 86 400 samples over 8 GPUs = 1 Mi channels per GPU, 362 GB
+    of samples: more than HBM holds): the rank's channel range streamed in batches -- generate on the device, encode,
+    decode, compare with the input -- one step = the whole range.  No data leaves the GPU; no collective."""
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dca = load_package()
+    ctx = dca.Context(local_rank)
+    C_, T, B = args.channels, args.samples, min(args.batch_channels, args.channels)
+    cap = 4 * int((T * args.cap_bytes_per_sample + 67) // 4)
+    x = torch.empty((T, B), dtype=torch.int32, device=dev)
+    y = torch.empty((T, B), dtype=torch.int32, device=dev)
+    out = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    bits = torch.zeros(B, dtype=torch.int64, device=dev)
+    err = torch.zeros(B, dtype=torch.int32, device=dev)
+    derr = torch.zeros(B, dtype=torch.int32, device=dev)
+    nbatch = (C_ + B - 1) // B
+
+    def one_pass(check):
+        ok, enc_ms, dec_ms, out_bytes = True, 0.0, 0.0, 0
+        for b in range(nbatch):
+            c0, n = b * B, min(B, C_ - b * B)
+            xs, ys = x[:, :n], y[:, :n]
+            if n != B:  # a ragged last batch: contiguous views of its own
+                xs, ys = torch.empty((T, n), dtype=torch.int32, device=dev), torch.empty((T, n), dtype=torch.int32, device=dev)
+            ctx.synth(n, T, seed=1234, c0=rank * C_ + c0, S=args.step_size, out=xs)
+            torch.cuda.synchronize()
+            ctx.profile(True)
+            ctx.encode(xs, adaptive=1, cap=cap, out=out[:n], bits=bits[:n], err=err[:n])
+            ctx.decode(out[:n], bits[:n], T, adaptive=1, x_tc=ys, err=derr[:n])
+            torch.cuda.synchronize()
+            ctx.profile(False)
+            enc_ms += ctx.profile_read(0)[1]
+            dec_ms += ctx.profile_read(1)[1]
+            if check:
+                ok = ok and bool((ys == xs).all().item()) and int((err[:n] != 0).sum().item()) == 0 and int((derr[:n] != 0).sum().item()) == 0
+                out_bytes += int(((bits[:n] + 7) // 8).sum().item())
+        return ok, enc_ms, dec_ms, out_bytes
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass(False)
+    barrier()
+    t0 = time.perf_counter()
+    ok, enc_ms, dec_ms, out_bytes = True, 0.0, 0.0, 0
+    for _ in range(args.steps):
+        o, e, d, ob = one_pass(True)
+        ok, enc_ms, dec_ms, out_bytes = ok and o, enc_ms + e, dec_ms + d, ob
+    barrier()
+    elapsed = time.perf_counter() - t0
+    vals = torch.tensor([elapsed, enc_ms, dec_ms, 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+    elapsed, enc_ms, dec_ms, bad = [float(v) for v in vals.tolist()]
+    if rank == 0:
+        kernel_s = (enc_ms + dec_ms) * 1e-3
+        algo = 2.0 * (4.0 * C_ * T + out_bytes)  # encode: samples in + stream out; decode: the reverse
+        res = {
+            "metric": "Msamples/s DEGA encode+decode round trip (int32)", "value": round(C_ * T * args.steps * world / kernel_s / 1e6, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(kernel_s / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "DEGA encode + decode + compare, %d channels x %d int32 samples per GPU streamed in %d batches of %d channels (generated on the device)" % (C_, T, nbatch, B),
+                       "channels_per_gpu": C_, "samples_per_channel": T, "batch_channels": B, "random_walk_step": args.step_size, "seed": 1234,
+                       "bits_per_sample_out": round(out_bytes * 8.0 / (C_ * T), 4), "partitioning": "channel ranges per GPU, batches per range, no collective",
+                       "value_counts": "the encode and decode kernels' time (hipEvents, summed over the batches); generation and comparison are outside it",
+                       "wall_ms_per_step_with_generation_and_compare": round(elapsed / args.steps * 1e3, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(algo * args.steps / kernel_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo * args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "dega_encode_kernel + dega_decode_kernel",
+                         "encode_ms_per_step": round(enc_ms / args.steps, 3), "decode_ms_per_step": round(dec_ms / args.steps, 3)},
+            "round_trip": {"bit_exact": bad == 0.0},
+        }
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
