@@ -159,3 +159,20 @@ def test_lzmh_cfg4_workload_device_resident(ctx, dca):
         n = int(lens[c].item())
         r, b, nb = orc.stage("lzmh", True, text[c, :n].cpu().numpy().tobytes(), 8 * n)
         assert r == 0 and int(bits[c].item()) == nb and out[c, : (nb + 7) // 8].cpu().numpy().tobytes() == b[: (nb + 7) // 8], c
+
+
+def test_lzmh_long_channels_count_saturation_and_long_runs(ctx):
+    """1.5 MB of random digits (the list counts run into their 65 535 cap, lzmh.c:304) and 600 kB of zeros (a 274-byte
+    match per step: the window-reload-and-retry path all the way), next to short channels in the same wave."""
+    rng = np.random.default_rng(42)
+    strings = [bytes(rng.integers(48, 58, 1_500_000, dtype=np.uint8)), bytes(600_000), b"12.50\n" * 50, b""]
+    out, bits, err = ctx.lzmh_encode_host(strings)
+    assert (err == 0).all()
+    for i, s in enumerate(strings):
+        r, b, n = orc.stage("lzmh", True, s, 8 * len(s))
+        assert r == 0 and int(bits[i]) == n and out[i, : (n + 7) // 8].tobytes() == b[: (n + 7) // 8], i
+    dec, lens, derr = ctx.lzmh_decode_host(out, bits, 1_500_008)
+    assert (derr == 0).all()
+    for i, s in enumerate(strings[:3]):
+        assert int(lens[i]) == len(s) and dec[i, : len(s)].tobytes() == s, i
+    assert int(lens[3]) == 1  # the reference's decoder turns the empty stream into one zero byte (lzmh.json: digits_0)

@@ -84,3 +84,16 @@ def test_lzmh_restatement_equals_compiled_reference_on_random_inputs():
         d = orc.stage("lzmh", False, g, 8 * len(g))
         dr = orc.ref_run_chain(g, 8 * len(g), ["decode lzmh"])
         assert (d[0], d[2]) == (dr[0], dr[2]), it
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_lzmh_restatement_equals_compiled_reference_on_long_inputs():
+    """Count saturation at 65 535 (lzmh.c:304) and back-to-back 274-byte matches: beyond what the short fixtures reach."""
+    rng = np.random.default_rng(42)
+    for data in (bytes(rng.integers(48, 58, 1_500_000, dtype=np.uint8)), bytes(600_000)):
+        a = orc.stage("lzmh", True, data, 8 * len(data))
+        r = orc.ref_run_chain(data, 8 * len(data), ["encode lzmh"])
+        assert a == (r[0], r[1], r[2])
+        d = orc.stage("lzmh", False, a[1], a[2])
+        dr = orc.ref_run_chain(a[1], a[2], ["decode lzmh"])
+        assert d == (dr[0], dr[1], dr[2]) and d[1] == data
