@@ -648,17 +648,28 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
           i = LZ_TREE; // the code is cut off by the end of the stream: no table entry matches (lzmh.c:423)
         if (i == LZ_TREE)
           break; // unknown code: the reference returns NO_ERROR here
-        const uint32_t sym = LZ_SYM8(i);
+        // the entry, its count and the two entries in front of it in one round of LDS reads (the bubble-up rarely goes further)
+        const uint32_t p1 = i > 0 ? i - 1u : 0u, p2 = i > 1 ? i - 2u : 0u;
+        const uint32_t sym = LZ_SYM8(i), c0 = LZ_CNT(i), c1 = LZ_CNT(p1), c2 = LZ_CNT(p2), s1 = LZ_SYM8(p1), s2 = LZ_SYM8(p2);
         code_length -= (int32_t)len;
         code_sym <<= len;
         LZ_EMIT(sym);
-        const uint32_t c0 = LZ_CNT(i);
         if (c0 < 65535u)
         {
-          while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+          if (i > 0 && c0 + 1u > c1)
           {
-            LZ_SYM8(i) = LZ_SYM8(i - 1u);
+            LZ_SYM8(i) = (uint8_t)s1;
             i--;
+            if (i > 0 && c0 + 1u > c2)
+            {
+              LZ_SYM8(i) = (uint8_t)s2;
+              i--;
+              while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+              {
+                LZ_SYM8(i) = LZ_SYM8(i - 1u);
+                i--;
+              }
+            }
           }
           LZ_CNT(i) = (uint16_t)(c0 + 1u);
           LZ_SYM8(i) = (uint8_t)sym;
