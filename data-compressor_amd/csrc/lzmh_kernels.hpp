@@ -1,4 +1,5 @@
-// lzmh_kernels.hpp -- LZMH encode (BASELINE config 4) for gfx950: the reference's second codec, DCLib/src/lzmh.c:130-370.
+// lzmh_kernels.hpp -- LZMH (BASELINE config 4) for gfx950: the reference's second codec, DCLib/src/lzmh.c:130-574.
+// Encode kernel first (this comment), decode kernel and the ASCII rendering of the workload further down.
 //
 // Mapping: one lane = one channel (an independent byte string), one wave = 64 channels, one workgroup = 4 waves.
 // The codec is serial per channel (every code depends on the match window, the recent-offset cache and the frequency
@@ -15,11 +16,11 @@
 //            and a byte-parallel compare marks every position whose first three bytes equal the next three input bytes:
 //            per dword 2 v_alignbyte, 3 xor, or3, a zero-byte test and a multiply that gathers the four flags -- 11
 //            instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
-//   phase 2  candidates are popped nearest first (= ascending offset); one whose byte at the current best length
-//            differs is dropped after one LDS byte read (the reference's own pruning test, :199-200), the others are
-//            measured 16 bytes at a time.
+//   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass, and each is
+//            measured against the 16 input bytes held in registers (all LDS reads of a pass in flight together);
+//            `len > best` in that order keeps the nearest of equals.
 // Window: 448 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for the whole wave when a lane
-// runs out of look-ahead (every ~300 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count})
+// runs out of look-ahead (every ~270 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count})
 // and four staged output words per lane are in LDS as well: 152 KiB per workgroup, one workgroup per CU.
 //
 // Compiled by hipcc (dega_hip.hip) and, for offline debugging only, by g++ under tests/sim/.
