@@ -547,11 +547,17 @@ struct LzmhDecodeArgs
   int32_t *err;            // [C]
 };
 
+// LPW = channels per wave.  The decoder is a chain of dependent LDS round trips (VALUBusy 28 % with one wave per SIMD), so
+// when a batch has no more waves than the GPU has SIMDs (up to 64 Ki channels) it runs with half-filled waves, 32
+// channels each: twice as many waves, two per SIMD (two 68 KiB workgroups fit a CU), and one hides the other's latency.
+// A half-empty wave costs its full VALU cycles -- affordable exactly because the VALU is mostly idle here.
+template <uint32_t LPW = 64>
 __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a)
 {
   __shared__ uint32_t lds[LZD_LDS_DW];
   const uint32_t tid = threadIdx.x;
-  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + tid;
+  const size_t c = LPW == 64 ? (size_t)blockIdx.x * LZ_BLOCK + tid
+                             : (size_t)blockIdx.x * (4u * LPW) + (tid >> 6) * LPW + ((tid & 63u) < LPW ? (tid & 63u) : a.C);
   uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + tid);
   uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_SYM + tid);
   uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZD_OFF_CNT + tid);
