@@ -222,10 +222,7 @@ extern "C" __attribute__((visibility("default"))) int sim_lzmh_render(const int3
 extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
 {
   LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
-  if (C % 3 == 0) // exercise both wave fillings
-    sim::launch(lzmh_decode_kernel<32>, dim3((unsigned)((C + 127) / 128)), dim3(LZ_BLOCK), a);
-  else
-    sim::launch(lzmh_decode_kernel<64>, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
+  sim::launch(lzmh_decode_kernel<64>, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
   return 0;
 }
 
@@ -276,5 +273,13 @@ extern "C" __attribute__((visibility("default"))) int sim_decode64(const uint8_t
     sim::launch(dega_decode_kernel<true, false, 4, true>, grid, dim3(BLOCK), a);
   else
     sim::launch(dega_decode_kernel<false, false, 4, true>, grid, dim3(BLOCK), a);
+  return 0;
+}
+
+// the half-filled-wave launch the library uses for up to 64 Ki channels
+extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode_half(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
+{
+  LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
+  sim::launch(lzmh_decode_kernel<32>, dim3((unsigned)((C + 127) / 128)), dim3(LZ_BLOCK), a);
   return 0;
 }
