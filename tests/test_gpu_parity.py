@@ -338,3 +338,40 @@ def test_static_model_and_float_entry_batch(ctx):
         back, derr = ctx.decode_f32_host(out, bits, T, factor=100.0, adaptive=ad)
         ints = np.frombuffer(orc.stage("normalize", True, np.ascontiguousarray(v[:, 0]).tobytes(), T * 32)[1], dtype=">i4")
         assert (derr == 0).all() and back[:, 0].tobytes() == (ints.astype(np.float32) / np.float32(100.0)).astype(np.float32).tobytes()
+
+
+def test_row_pitch_and_alignment_variants(ctx):
+    """The encoder fetches rows four at a time when a wave's 64 channels all exist, the pitch is a multiple of 4 and the
+    base is 16-byte aligned, else one dword per lane; the decoder writes rows with the caller's pitch.  Both paths, with
+    ld > C, odd pitches, a misaligned base and a ragged last wave, against the oracle; the columns beyond C stay untouched."""
+    import torch
+    rng = np.random.default_rng(17)
+    for Cn, ld, off in ((128, 128, 0), (128, 131, 0), (128, 132, 1), (100, 160, 0), (64, 64, 2), (320, 323, 3)):
+        T = 160
+        x = (np.cumsum(rng.integers(-60, 61, (T, Cn)), axis=0) + 30000).astype(np.int32)
+        flat = torch.full((T * ld + 8,), -7, dtype=torch.int32, device="cuda")
+        view = flat[off: off + T * ld].view(T, ld)  # base misaligned by `off` dwords
+        view[:, :Cn] = torch.from_numpy(x).cuda()
+        cap = 4 * ((orc.lib().orc_dega_worst_case_bytes(T) + 3) // 4)
+        out = torch.zeros((Cn, cap), dtype=torch.uint8, device="cuda")
+        bits = torch.zeros(Cn, dtype=torch.int64, device="cuda")
+        err = torch.zeros(Cn, dtype=torch.int32, device="cuda")
+        lib = ctx_lib()
+        ret = lib.dega_hip_encode_dev(ctx._h, view.data_ptr(), Cn, T, ld, 1, 32, out.data_ptr(), cap, bits.data_ptr(), err.data_ptr(), None)
+        assert ret == 0
+        torch.cuda.synchronize()
+        want_out, want_bits, want_err = orc.encode_batch_tc(x, 1, cap=cap)
+        assert_streams_equal(out.cpu().numpy(), bits.cpu().numpy().astype(np.uint64), err.cpu().numpy(), want_out, want_bits, want_err, (Cn, ld, off))
+        yflat = torch.full((T * ld + 8,), -9, dtype=torch.int32, device="cuda")
+        yview = yflat[off: off + T * ld].view(T, ld)
+        derr = torch.zeros(Cn, dtype=torch.int32, device="cuda")
+        ret = lib.dega_hip_decode_dev(ctx._h, out.data_ptr(), cap, bits.data_ptr(), Cn, T, ld, 1, 32, yview.data_ptr(), derr.data_ptr(), None)
+        assert ret == 0
+        torch.cuda.synchronize()
+        got = yview.cpu().numpy()
+        assert (derr.cpu().numpy() == 0).all() and (got[:, :Cn] == x).all(), (Cn, ld, off)
+        assert (got[:, Cn:] == -9).all(), "the decoder wrote outside its C columns"
+
+
+def ctx_lib():
+    return load_package().library()
