@@ -239,9 +239,15 @@ def main():
             t0 = time.perf_counter()
             ho, hb, he = ctx.encode_host(xh, adaptive=1, cap=cap)
             dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            pk, poff, pb, pe = ctx.encode_packed_host(xh, adaptive=1)
+            dtp = time.perf_counter() - t0
             res["end_to_end"] = {"value": round(n * T / dt / 1e6, 2), "unit": "Msamples/s", "channels": n, "seconds": round(dt, 3),
                                  "what": "dega_hip_encode_host: device alloc + H2D of pageable memory + kernel + D2H of the slabs",
-                                 "streams_equal_device_resident": bool((hb.astype(np.int64) == bits[:n].cpu().numpy()).all())}
+                                 "packed_value": round(n * T / dtp / 1e6, 2), "packed_seconds": round(dtp, 3),
+                                 "packed_what": "dega_hip_encode_packed_host: the same with the streams compacted on the device before D2H",
+                                 "streams_equal_device_resident": bool((hb.astype(np.int64) == bits[:n].cpu().numpy()).all()
+                                                                       and (pb.astype(np.int64) == bits[:n].cpu().numpy()).all())}
         print(json.dumps(res), flush=True)
     if pool is not None:
         pool.close()

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "dega_hip_compact_gather_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _P]),
     "dega_hip_synth_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "dega_hip_encode_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P]),
+    "dega_hip_encode_packed_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
     "dega_hip_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P]),
     "dega_hip_decode_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
@@ -315,6 +316,26 @@ class Context:
         ret = library().dega_hip_encode_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), int(valuesize), out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
         self._check(ret, "dega_hip_encode_host")
         return out, bits, err
+
+    def encode_packed_host(self, x_tc, adaptive=1, valuesize=32, packed_cap=None):
+        """Streams returned packed: (packed uint8 [total], offsets uint64 [C+1], bits uint64 [C], err int32 [C])."""
+        import numpy as np
+        x_tc = np.ascontiguousarray(x_tc, dtype=np.int32)
+        T, Cn = x_tc.shape
+        if packed_cap is None:
+            packed_cap = Cn * (T * 2 + 64)  # 2 bytes per sample: generous for meter data; the call says so if it is not
+        offsets = np.zeros(Cn + 1, dtype=np.uint64)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        for _ in range(2):
+            packed = np.empty(max(1, packed_cap), dtype=np.uint8)
+            ret = library().dega_hip_encode_packed_host(self._h, x_tc.ctypes.data, Cn, T, Cn, int(adaptive), int(valuesize), packed.ctypes.data,
+                                                        packed_cap, offsets.ctypes.data, bits.ctypes.data, err.ctypes.data)
+            if ret != ERROR_MEMORY or int(offsets[Cn]) <= packed_cap:
+                break
+            packed_cap = int(offsets[Cn])
+        self._check(ret, "dega_hip_encode_packed_host")
+        return packed[: int(offsets[Cn])], offsets, bits, err
 
     def decode_host(self, streams, bits, T, adaptive=1, valuesize=32):
         import numpy as np

@@ -918,3 +918,41 @@ extern "C" int dega_hip_decode64_var_host(dega_hip_ctx *ctx, const uint8_t *in, 
   HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }
+
+extern "C" int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                           uint8_t *packed, size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err)
+{
+  int ret;
+  const size_t cap = dega_hip_worst_case_bytes(T);
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (offsets == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  offsets[0] = 0;
+  if (C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  DevBuf dx, dout, dbits, derr, doff, dpacked;
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, doff.alloc((C + 1) * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  if ((ret = dega_hip_compact_offsets_dev(ctx, (const uint64_t *)dbits.p, C, (uint64_t *)doff.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipMemcpy(offsets, doff.p, (C + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  if (offsets[C] > packed_cap)
+    return fail(ctx, DEGA_ERROR_MEMORY, "packed buffer too small: offsets[C] holds the size needed", hipSuccess);
+  if (offsets[C] == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, dpacked.alloc((size_t)offsets[C]), DEGA_ERROR_MEMORY);
+  if ((ret = dega_hip_compact_gather_dev(ctx, (const uint8_t *)dout.p, cap, (const uint64_t *)doff.p, C, (uint8_t *)dpacked.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipMemcpy(packed, dpacked.p, (size_t)offsets[C], hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}

@@ -148,7 +148,8 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   uint64_t *bits = NULL;
   int32_t *err = NULL;
   int32_t *x = NULL;
-  size_t T, cap, c, t;
+  size_t T, cap, c, t, packed_bytes = 0;
+  int packed_streams = 0;
   const size_t vs = options->value_size_bits;
   const size_t in_vs = is_float ? 32 : vs; /* normalize always reads 32-bit floats (normalize.c:15) */
   io_int_t ret;
@@ -222,7 +223,21 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
           w = (w << 8) | raw.p[(at >> 3) + k]; /* slurp() pads the buffer with 16 zero bytes */
         x[t] = (int32_t)((w >> (40 - (at & 7) - vs)) & (((uint64_t)1 << vs) - 1));
       }
-    ret = dega_hip_encode_host(ctx, x, C, T, C, options->adaptive, (int)vs, streams, cap, bits, err);
+    if (C > 1) /* the container wants the streams back to back: have them packed on the device, only they cross PCIe */
+    {
+      uint64_t *const offsets = (uint64_t *)calloc(C + 1, sizeof(uint64_t));
+      packed_streams = 1;
+      if (offsets == NULL)
+        ret = ERROR_MEMORY;
+      else
+      {
+        ret = dega_hip_encode_packed_host(ctx, x, C, T, C, options->adaptive, (int)vs, streams, C * cap, offsets, bits, err);
+        packed_bytes = (size_t)offsets[C];
+        free(offsets);
+      }
+    }
+    else
+      ret = dega_hip_encode_host(ctx, x, C, T, C, options->adaptive, (int)vs, streams, cap, bits, err);
   }
   if (ret != DEGA_OK)
   {
@@ -252,12 +267,18 @@ static io_int_t encode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
       if (WriteBitFileBuffer(out, head, 64) != 64)
         ret = ERROR_LIBRARY_CALL;
     }
-    for (c = 0; c < C && ret == NO_ERROR; c++)
+    if (packed_streams)
     {
-      const size_t nb = (size_t)((bits[c] + 7) / 8) * 8;
-      if (WriteBitFileBuffer(out, streams + c * cap, nb) != (io_int_t)nb)
+      if (ret == NO_ERROR && WriteBitFileBuffer(out, streams, 8 * packed_bytes) != (io_int_t)(8 * packed_bytes))
         ret = ERROR_LIBRARY_CALL;
     }
+    else
+      for (c = 0; c < C && ret == NO_ERROR; c++)
+      {
+        const size_t nb = (size_t)((bits[c] + 7) / 8) * 8;
+        if (WriteBitFileBuffer(out, streams + c * cap, nb) != (io_int_t)nb)
+          ret = ERROR_LIBRARY_CALL;
+      }
   }
 done:
   free(raw.p);

@@ -143,6 +143,12 @@ int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
                          int adaptive, int valuesize, int32_t *x_tc, int32_t *err);
 int dega_hip_decode_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
                              int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
+/* The same encode, streams returned packed: channel c occupies packed[offsets[c] .. offsets[c+1]) -- ceil(bits/8) bytes, in
+   channel order, which is how DCCLI-style callers concatenate them anyway -- so only the stream bytes cross PCIe, not
+   C x cap slab bytes.  offsets has C + 1 entries; if packed_cap is too small the call returns DEGA_ERROR_MEMORY with the
+   size needed in offsets[C] (bits and err are valid then). */
+int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
+                                uint8_t *packed, size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err);
 /* float32 channels in, DEGA streams out: normalize + encode fused on the device (and the inverse). */
 int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
                              uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);

@@ -375,3 +375,25 @@ def test_row_pitch_and_alignment_variants(ctx):
 
 def ctx_lib():
     return load_package().library()
+
+
+def test_packed_host_entry_equals_slabs(ctx, dca):
+    """dega_hip_encode_packed_host: the streams of encode_host, concatenated (ceil(bits/8) bytes each, channel order)."""
+    rng = np.random.default_rng(23)
+    T, Cn = 700, 300
+    x = (np.cumsum(rng.integers(-80, 81, (T, Cn)), axis=0) + 25000).astype(np.int32)
+    x[3, 7] = -1  # a channel in error (a negative sample is read as 2^32 - 1: the difference does not fit, diff.c:15-18)
+    out, bits, err = ctx.encode_host(x, adaptive=1)
+    packed, offsets, pbits, perr = ctx.encode_packed_host(x, adaptive=1)
+    assert (pbits == bits).all() and (perr == err).all() and err[7] != 0
+    assert int(offsets[0]) == 0 and int(offsets[Cn]) == len(packed) == int(((bits + 7) // 8).sum())
+    for c in range(Cn):
+        nb = (int(bits[c]) + 7) // 8
+        assert int(offsets[c + 1] - offsets[c]) == nb and packed[int(offsets[c]): int(offsets[c]) + nb].tobytes() == out[c, :nb].tobytes(), c
+    # a buffer that is too small: the size needed is reported
+    small, off2, _, _ = None, np.zeros(Cn + 1, dtype=np.uint64), None, None
+    b2 = np.zeros(Cn, dtype=np.uint64)
+    e2 = np.zeros(Cn, dtype=np.int32)
+    buf = np.empty(16, dtype=np.uint8)
+    ret = dca.library().dega_hip_encode_packed_host(ctx._h, x.ctypes.data, Cn, T, Cn, 1, 32, buf.ctypes.data, 16, off2.ctypes.data, b2.ctypes.data, e2.ctypes.data)
+    assert ret == dca.ERROR_MEMORY and int(off2[Cn]) == len(packed) and (b2 == bits).all()
