@@ -1,31 +1,2 @@
-/* bit_file_buffer.h -- bit-granular stream I/O.  Public names and semantics follow the reference's
-   DCIOLib/inc/bit_file_buffer.h:12-33; the format it defines is what the GPU kernels reproduce:
-     - bits fill a byte from its most significant bit (DCIOLib/src/bit_file_buffer.c:220-248)
-     - an n-bit value is written most significant bit first, so 32-bit values are big-endian (:297-308)
-     - a stream may end on a fractional byte; a write->read mode switch keeps the exact bit count (:127-144), a file
-       gets the last byte zero padded, and an empty output still writes one 0x00 byte (:310-333). */
-#ifndef DC_AMD_BIT_FILE_BUFFER_H
-#define DC_AMD_BIT_FILE_BUFFER_H
-
-#include "file_buffer.h"
-
-typedef struct bit_file_buffer_t bit_file_buffer_t;
-
-bit_file_buffer_t *AllocateBitFileBuffer(void);
-void FreeBitFileBuffer(bit_file_buffer_t *bit_file_buffer);
-void InitBitFileBuffer(bit_file_buffer_t *bit_file_buffer, file_buffer_t *file_buffer);
-void UninitBitFileBuffer(bit_file_buffer_t *bit_file_buffer);
-
-int EndOfBitFileBuffer(const bit_file_buffer_t *bit_file_buffer);
-void GetActualBitFileOffset(const bit_file_buffer_t *bit_file_buffer, io_int_t *byte_offset, uint8_t *bit_offset);
-int SetBitFileBufferMode(bit_file_buffer_t *bit_file_buffer, file_buffer_mode_t mode);
-int ResetBitFileBuffer(bit_file_buffer_t *bit_file_buffer, file_buffer_mode_t mode);
-
-/* bytes in memory order, output_bit_size bits (a trailing fraction is left aligned); return = bits transferred */
-io_int_t ReadBitFileBuffer(bit_file_buffer_t *bit_file_buffer, uint8_t *output, size_t output_bit_size);
-io_int_t WriteBitFileBuffer(bit_file_buffer_t *bit_file_buffer, const uint8_t *input, size_t input_bit_size);
-/* the low value_bit_size bits of *value, most significant first */
-io_int_t ReadSingleValueFromBitFileBuffer(bit_file_buffer_t *bit_file_buffer, io_uint_t *value, size_t value_bit_size);
-io_int_t WriteSingleValueToBitFileBuffer(bit_file_buffer_t *bit_file_buffer, const io_uint_t *value, size_t value_bit_size);
-
-#endif
+/* bit_file_buffer.h -- bit stream: see dclib_boundary.h (this name exists so that sources written for the reference find it) */
+#include "dclib_boundary.h"

@@ -1,35 +1,2 @@
-/* err_codes.h -- error codes of the codec library; same names and values as the reference's
-   common/inc/err_codes.h:8-39, because they are part of the plugin boundary (an enc_dec_function_t returns them and
-   DCCLI prints ERROR_MESSAGE_STRING(code), DCCLI/src/cli.c:447-453). */
-#ifndef DC_AMD_ERR_CODES_H
-#define DC_AMD_ERR_CODES_H
-
-#define NO_ERROR 0
-#define ERROR_INVALID_VALUE (-1)
-#define ERROR_VALUE_LARGER_THAN_USABLE_SIZE (-2)
-#define ERROR_INVALID_FORMAT (-3)
-#define ERROR_INVALID_MODE (-4)
-#define ERROR_FILE_IO (-5)
-#define ERROR_MEMORY (-6)
-#define ERROR_LIBRARY_INIT (-10)
-#define ERROR_LIBRARY_CALL (-11)
-
-static inline const char *dc_error_message(long code)
-{
-  switch (code)
-  {
-    case NO_ERROR: return "Successful";
-    case ERROR_INVALID_VALUE: return "Invalid value";
-    case ERROR_VALUE_LARGER_THAN_USABLE_SIZE: return "Value larger than usable size";
-    case ERROR_INVALID_FORMAT: return "Invalid format";
-    case ERROR_INVALID_MODE: return "Invalid mode";
-    case ERROR_FILE_IO: return "File I/O error";
-    case ERROR_MEMORY: return "Memory error";
-    case ERROR_LIBRARY_INIT: return "Error initializing library";
-    case ERROR_LIBRARY_CALL: return "Error calling library";
-    default: return "Unknown error";
-  }
-}
-#define ERROR_MESSAGE_STRING(code) dc_error_message((long)(code))
-
-#endif
+/* err_codes.h -- status codes: see dclib_boundary.h (this name exists so that sources written for the reference find it) */
+#include "dclib_boundary.h"

@@ -1,25 +1,2 @@
-/* file_buffer.h -- byte stream behind a bit buffer: a FILE or growable memory.  Public names follow the reference's
-   DCIOLib/inc/file_buffer.h:10-41 (the part DCCLI and the codecs use); the implementation (src/bit_io.c) is ours. */
-#ifndef DC_AMD_FILE_BUFFER_H
-#define DC_AMD_FILE_BUFFER_H
-
-#include "io.h"
-
-typedef enum file_buffer_mode_t
-{
-  FBM_INVALID = -1,
-  FBM_READING = 0,
-  FBM_WRITING = 1
-} file_buffer_mode_t;
-
-typedef struct file_buffer_t file_buffer_t;
-
-file_buffer_t *AllocateFileBuffer(void);
-void FreeFileBuffer(file_buffer_t *file_buffer);
-int InitFileBuffer(file_buffer_t *file_buffer, FILE *file, file_buffer_mode_t mode, size_t buffer_size);
-int InitFileBufferInMemory(file_buffer_t *file_buffer, file_buffer_mode_t mode, size_t buffer_size);
-void UninitFileBuffer(file_buffer_t *file_buffer);
-file_buffer_mode_t GetFileBufferMode(const file_buffer_t *file_buffer);
-size_t GetFileBufferSize(const file_buffer_t *file_buffer);
-
-#endif
+/* file_buffer.h -- byte stream: see dclib_boundary.h (this name exists so that sources written for the reference find it) */
+#include "dclib_boundary.h"
