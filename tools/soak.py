@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Randomised differential soak on the GPU: the HIP kernels against the oracle on random shapes, value sizes, models,
+workgroup shapes and damaged streams.  tools/soak.py [seconds] [seed]   (not a pytest: a longer hunt for rare cases)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+from oracle import orc  # noqa: E402
+from test_valuesize import pack_be, unpack_be  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dca = load_package()
+ctx = dca.Context(0)
+t_end = time.time() + budget
+rounds = checked = bad = 0
+
+
+def chain(x_col, vs, ad):
+    d, n = pack_be(x_col, vs)
+    for name in ("diff", "seg", "bac"):
+        r, d, n = orc.stage(name, True, d, n, valuesize=vs, adaptive=ad)
+        if r:
+            return r, b"", 0
+    return 0, d, n
+
+
+def unchain(d, n, vs, ad):
+    for name in ("bac", "seg", "diff"):
+        r, d, n = orc.stage(name, False, d, n, valuesize=vs, adaptive=ad)
+        if r:
+            return r, None
+    return 0, unpack_be(d, n, vs)
+
+
+while time.time() < t_end:
+    rounds += 1
+    vs = int(rng.choice([32, 32, 32, 16, 8, 24, 13, 31, 5]))
+    ad = int(rng.integers(0, 2))
+    Cn = int(rng.choice([1, 3, 64, 65, 200, 257, 700]))
+    T = int(rng.choice([0, 1, 2, 7, 33, 100, 257, 900]))
+    top = (1 << vs) - 1
+    kind = rng.integers(0, 4, Cn)
+    x = np.zeros((T, Cn), dtype=np.int64)
+    for c in range(Cn):
+        if T == 0:
+            break
+        if kind[c] == 0:
+            col = np.cumsum(rng.integers(-60, 61, T)) + top // 4
+        elif kind[c] == 1:
+            col = rng.integers(0, top + 1, T)
+        elif kind[c] == 2:
+            col = np.cumsum(rng.integers(-(top // 6 + 1), top // 6 + 2, T)) + top // 2
+        else:
+            col = np.where(rng.random(T) < 0.05, rng.integers(0, top + 1, T), top // 3)
+        x[:, c] = np.clip(col, 0, top)
+    xin = np.ascontiguousarray(x.astype(np.uint32).view(np.int32))
+    out, bits, err = ctx.encode_host(xin, adaptive=ad, valuesize=vs)
+    sel = rng.choice(Cn, size=min(Cn, 24), replace=False)
+    for c in sel:
+        r, d, n = chain(x[:, c], vs, ad)
+        checked += 1
+        if r != err[c] or (r == 0 and (n != int(bits[c]) or out[c, : (n + 7) // 8].tobytes() != d[: (n + 7) // 8])):
+            bad += 1
+            print("ENCODE MISMATCH", dict(vs=vs, ad=ad, C=Cn, T=T, c=int(c), want=(r, n), got=(int(err[c]), int(bits[c]))), flush=True)
+    ok = err == 0
+    if ok.any() and T > 0:
+        dmg = out.copy()
+        dbits = np.where(ok, bits, 0).astype(np.uint64)
+        hurt = rng.random(Cn) < 0.3
+        for c in np.nonzero(hurt & ok)[0]:
+            nb = int(dbits[c])
+            if nb > 0:
+                k = int(rng.integers(0, nb))
+                dmg[c, k // 8] ^= 0x80 >> (k % 8)
+        room = 4 * T + 64
+        y, counts, derr = ctx.decode_var_host(dmg, dbits, room, adaptive=ad, valuesize=vs)
+        for c in sel:
+            if not ok[c]:
+                continue
+            nb = int(dbits[c])
+            r, want = unchain(dmg[c, : (nb + 7) // 8].tobytes(), nb, vs, ad)
+            checked += 1
+            if r != 0 and derr[c] == dca.ERROR_MEMORY:
+                continue  # ran out of room before the stage-wise chain's failure point
+            if r == 0 and len(want) > room:
+                if derr[c] != dca.ERROR_MEMORY:
+                    bad += 1
+                    print("DECODE ROOM MISMATCH", dict(vs=vs, ad=ad, c=int(c)), flush=True)
+                continue
+            if derr[c] != r or (r == 0 and (int(counts[c]) != len(want) or (y[: len(want), c].view(np.uint32) != want).any())):
+                bad += 1
+                print("DECODE MISMATCH", dict(vs=vs, ad=ad, C=Cn, T=T, c=int(c), hurt=bool(hurt[c]), want=r, got=int(derr[c])), flush=True)
+    # LZMH on random strings
+    strings = []
+    for i in range(int(rng.choice([1, 5, 70]))):
+        n = int(rng.choice([0, 1, 3, 402, 403, 404, 700, 2500]))
+        k = rng.integers(0, 4)
+        if k == 0:
+            s = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        elif k == 1:
+            s = "".join("%.2f\n" % v for v in 230 + np.cumsum(rng.normal(0, 0.3, n // 6 + 1))).encode()[:n]
+        elif k == 2:
+            s = bytes(rng.integers(0, 3, n, dtype=np.uint8))
+        else:
+            s = (bytes(rng.integers(97, 100, 9, dtype=np.uint8)) * (n // 9 + 1))[:n]
+        strings.append(s)
+    lout, lbits, lerr = ctx.lzmh_encode_host(strings)
+    for i, s in enumerate(strings):
+        r, b, n = orc.stage("lzmh", True, s, 8 * len(s))
+        checked += 1
+        if lerr[i] != 0 or int(lbits[i]) != n or lout[i, : (n + 7) // 8].tobytes() != b[: (n + 7) // 8]:
+            bad += 1
+            print("LZMH ENCODE MISMATCH", i, len(s), flush=True)
+    ldmg = lout.copy()
+    for i in range(len(strings)):
+        nb = int(lbits[i])
+        if nb > 8 and rng.random() < 0.3:
+            k = int(rng.integers(0, nb))
+            ldmg[i, k // 8] ^= 0x80 >> (k % 8)
+    dec, lens, derr = ctx.lzmh_decode_host(ldmg, lbits, 32768)
+    for i in range(len(strings)):
+        nb = int(lbits[i])
+        r, d, dn = orc.stage("lzmh", False, ldmg[i, : (nb + 7) // 8].tobytes(), nb)
+        checked += 1
+        if dn // 8 > 32768:
+            continue
+        if derr[i] != r or int(lens[i]) != dn // 8 or dec[i, : dn // 8].tobytes() != d[: dn // 8]:
+            bad += 1
+            print("LZMH DECODE MISMATCH", i, len(strings[i]), int(derr[i]), r, int(lens[i]), dn // 8, flush=True)
+    if rounds % 20 == 0:
+        print("rounds", rounds, "checked", checked, "bad", bad, flush=True)
+print("SOAK DONE rounds", rounds, "checked", checked, "bad", bad)
+ctx.close()
+sys.exit(1 if bad else 0)
