@@ -15,6 +15,7 @@ from test_valuesize import pack_be, unpack_be  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"  # batches of more than 64 Ki channels: the 8-wave workgroup shapes
 dca = load_package()
 ctx = dca.Context(0)
 t_end = time.time() + budget
@@ -42,12 +43,16 @@ while time.time() < t_end:
     rounds += 1
     vs = int(rng.choice([32, 32, 32, 16, 8, 24, 13, 31, 5]))
     ad = int(rng.integers(0, 2))
-    Cn = int(rng.choice([1, 3, 64, 65, 200, 257, 700]))
-    T = int(rng.choice([0, 1, 2, 7, 33, 100, 257, 900]))
+    Cn = int(rng.choice([65537, 70001, 131072 + 77])) if WIDE else int(rng.choice([1, 3, 64, 65, 200, 257, 700]))
+    T = int(rng.choice([1, 9, 40, 130])) if WIDE else int(rng.choice([0, 1, 2, 7, 33, 100, 257, 900]))
     top = (1 << vs) - 1
     kind = rng.integers(0, 4, Cn)
     x = np.zeros((T, Cn), dtype=np.int64)
-    for c in range(Cn):
+    if WIDE and T > 0:  # vectorised generation for the large batches: walks, with every 16th channel jumping around
+        x = np.cumsum(rng.integers(-60, 61, (T, Cn)), axis=0) + top // 4
+        x[:, ::16] = rng.integers(0, top + 1, (T, (Cn + 15) // 16))
+        x = np.clip(x, 0, top)
+    for c in range(0 if not WIDE else Cn, Cn):
         if T == 0:
             break
         if kind[c] == 0:
@@ -98,7 +103,7 @@ while time.time() < t_end:
                 print("DECODE MISMATCH", dict(vs=vs, ad=ad, C=Cn, T=T, c=int(c), hurt=bool(hurt[c]), want=r, got=int(derr[c])), flush=True)
     # LZMH on random strings
     strings = []
-    for i in range(int(rng.choice([1, 5, 70]))):
+    for i in range(0 if WIDE else int(rng.choice([1, 5, 70]))):
         n = int(rng.choice([0, 1, 3, 402, 403, 404, 700, 2500]))
         k = rng.integers(0, 4)
         if k == 0:
@@ -110,6 +115,10 @@ while time.time() < t_end:
         else:
             s = (bytes(rng.integers(97, 100, 9, dtype=np.uint8)) * (n // 9 + 1))[:n]
         strings.append(s)
+    if not strings:
+        if rounds % 5 == 0:
+            print("rounds", rounds, "checked", checked, "bad", bad, flush=True)
+        continue
     lout, lbits, lerr = ctx.lzmh_encode_host(strings)
     for i, s in enumerate(strings):
         r, b, n = orc.stage("lzmh", True, s, 8 * len(s))
