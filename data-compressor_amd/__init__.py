@@ -47,6 +47,7 @@ _SIGNATURES = {
     "dega_hip_synth_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "dega_hip_encode_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P]),
     "dega_hip_encode_packed_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
+    "dega_hip_decode_packed_host": (C.c_int, [_P, _P, _P, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P]),
     "dega_hip_decode_var_host": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_int, C.c_int, _P, _P, _P]),
     "dega_hip_encode_f32_host": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P]),
@@ -336,6 +337,21 @@ class Context:
             packed_cap = int(offsets[Cn])
         self._check(ret, "dega_hip_encode_packed_host")
         return packed[: int(offsets[Cn])], offsets, bits, err
+
+    def decode_packed_host(self, packed, offsets, bits, T, adaptive=1, valuesize=32, var=False):
+        """The inverse of encode_packed_host.  Returns (x int32 [T, C], err) or, with var=True, (x, counts, err)."""
+        import numpy as np
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn = bits.size
+        x = np.zeros((T, Cn), dtype=np.int32)
+        counts = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_decode_packed_host(self._h, packed.ctypes.data, offsets.ctypes.data, bits.ctypes.data, Cn, T, Cn, int(adaptive),
+                                                    int(valuesize), x.ctypes.data, counts.ctypes.data if var else None, err.ctypes.data)
+        self._check(ret, "dega_hip_decode_packed_host")
+        return (x, counts, err) if var else (x, err)
 
     def decode_host(self, streams, bits, T, adaptive=1, valuesize=32):
         import numpy as np

@@ -956,3 +956,52 @@ extern "C" int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_t
   HIP_TRY(ctx, hipMemcpy(packed, dpacked.p, (size_t)offsets[C], hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }
+
+extern "C" int dega_hip_decode_packed_host(dega_hip_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, size_t T,
+                                           size_t ld, int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
+{
+  int ret;
+  if (ctx == nullptr || offsets == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  uint64_t longest = 0;
+  for (size_t c = 0; c < C; c++)
+  {
+    if (offsets[c + 1] < offsets[c] || (in_bits[c] + 7) / 8 > offsets[c + 1] - offsets[c])
+      return fail(ctx, DEGA_ERROR_INVALID_VALUE, "offsets must grow and hold ceil(bits / 8) bytes per channel", hipSuccess);
+    longest = offsets[c + 1] - offsets[c] > longest ? offsets[c + 1] - offsets[c] : longest;
+  }
+  const size_t cap = ((size_t)longest + 16 + 3) & ~(size_t)3; // room for the decoder's word look-ahead
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  const size_t total = (size_t)offsets[C];
+  DevBuf dpacked, doff, dslabs, dbits, dx, dcnt, derr;
+  HIP_TRY(ctx, dpacked.alloc(total), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, doff.alloc((C + 1) * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dslabs.alloc(C * cap), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, dcnt.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
+  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
+  if (total > 0)
+    HIP_TRY(ctx, hipMemcpy(dpacked.p, packed, total, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(doff.p, offsets, (C + 1) * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
+  {
+    GatherArgs g{(const uint8_t *)dslabs.p, cap, (const uint64_t *)doff.p, C, (uint8_t *)dpacked.p};
+    hipLaunchKernelGGL(dega_scatter_kernel, dim3((unsigned)((C + WAVES - 1) / WAVES)), dim3(BLOCK), 0, nullptr, g);
+    HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  }
+  if ((ret = launch_decode(ctx, (const uint8_t *)dslabs.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
+                           out_count != nullptr ? (uint64_t *)dcnt.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
+    return ret;
+  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, T * ld * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  if (out_count != nullptr)
+    HIP_TRY(ctx, hipMemcpy(out_count, dcnt.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}

@@ -908,4 +908,19 @@ __global__ void __launch_bounds__(256) dega_gather_kernel(const GatherArgs a)
     dst[i] = src[i];
 }
 
+// the inverse: packed streams -> slabs (the decoders mask what lies beyond a stream's bit length, so nothing is padded)
+__global__ void __launch_bounds__(256) dega_scatter_kernel(const GatherArgs a)
+{
+  const size_t c = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (c >= a.C)
+    return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t o0 = a.offsets[c], o1 = a.offsets[c + 1];
+  const uint8_t *src = a.packed + o0;
+  uint8_t *dst = const_cast<uint8_t *>(a.slabs) + c * a.cap;
+  const uint64_t n = o1 - o0 < a.cap ? o1 - o0 : a.cap;
+  for (uint64_t i = lane; i < n; i += 64)
+    dst[i] = src[i];
+}
+
 } // namespace dg

@@ -308,10 +308,10 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
   byte_vec raw = { NULL, 0, 0 };
   uint64_t nbits = 0;
   uint8_t *streams = NULL;
-  uint64_t *bits = NULL, *counts = NULL;
+  uint64_t *bits = NULL, *counts = NULL, *offsets = NULL;
   int32_t *err = NULL;
   int32_t *x = NULL;
-  size_t C = 1, T = 0, cap = 0, c, t;
+  size_t C = 1, T = 0, cap = 0, c, t, packed_at = 0;
   const size_t vs = options->value_size_bits;
   int known_T = 0;
   io_int_t ret;
@@ -355,23 +355,43 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
         cap = (size_t)((bits[c] + 7) / 8);
     }
     cap = (cap + 16 + 3) & ~(size_t)3;
-    streams = (uint8_t *)calloc(C, cap);
-    if (streams == NULL)
-    {
-      ret = ERROR_MEMORY;
-      goto done;
-    }
     off = 24 + 8 * C;
-    for (c = 0; c < C; c++)
+    if (!is_float && vs <= 32) /* the container's stream area is the packed form: hand it over as it is */
     {
-      const size_t nb = (size_t)((bits[c] + 7) / 8);
-      if (off + nb > raw.n)
+      offsets = (uint64_t *)calloc(C + 1, sizeof(uint64_t));
+      if (offsets == NULL)
+      {
+        ret = ERROR_MEMORY;
+        goto done;
+      }
+      for (c = 0; c < C; c++)
+        offsets[c + 1] = offsets[c] + (bits[c] + 7) / 8;
+      if (off + offsets[C] > raw.n)
       {
         ret = ERROR_INVALID_FORMAT;
         goto done;
       }
-      memcpy(streams + c * cap, raw.p + off, nb);
-      off += nb;
+      packed_at = off;
+    }
+    else
+    {
+      streams = (uint8_t *)calloc(C, cap);
+      if (streams == NULL)
+      {
+        ret = ERROR_MEMORY;
+        goto done;
+      }
+      for (c = 0; c < C; c++)
+      {
+        const size_t nb = (size_t)((bits[c] + 7) / 8);
+        if (off + nb > raw.n)
+        {
+          ret = ERROR_INVALID_FORMAT;
+          goto done;
+        }
+        memcpy(streams + c * cap, raw.p + off, nb);
+        off += nb;
+      }
     }
   }
   else /* a bare stream: the sample count is only implied by the EOF symbol (bac.c:256) */
@@ -403,7 +423,9 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
       ret = ERROR_MEMORY;
       goto done;
     }
-    if (vs > 32) /* 64-bit containers: the variable-length entry serves both cases */
+    if (offsets != NULL) /* container of int32-sized values: packed streams in, only they cross PCIe */
+      ret = dega_hip_decode_packed_host(ctx, raw.p + packed_at, offsets, bits, C, T, C, options->adaptive, (int)vs, x, NULL, err);
+    else if (vs > 32) /* 64-bit containers: the variable-length entry serves both cases */
     {
       ret = dega_hip_decode64_var_host(ctx, streams, cap, bits, C, T, C, options->adaptive, (int)vs, (int64_t *)(void *)x, counts, err);
       if (ret == DEGA_OK && known_T)
@@ -451,6 +473,7 @@ done:
   free(raw.p);
   free(streams);
   free(bits);
+  free(offsets);
   free(counts);
   free(err);
   free(x);

@@ -149,6 +149,10 @@ int dega_hip_decode_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, c
    size needed in offsets[C] (bits and err are valid then). */
 int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                                 uint8_t *packed, size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err);
+/* The inverse: channel c's stream is packed[offsets[c] .. offsets[c+1]) (at least ceil(in_bits[c] / 8) bytes); out_count NULL
+   = every channel holds exactly T samples, else up to T and the counts are reported (as dega_hip_decode_var_host). */
+int dega_hip_decode_packed_host(dega_hip_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, size_t T,
+                                size_t ld, int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
 /* float32 channels in, DEGA streams out: normalize + encode fused on the device (and the inverse). */
 int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
                              uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);

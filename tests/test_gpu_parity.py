@@ -390,6 +390,12 @@ def test_packed_host_entry_equals_slabs(ctx, dca):
     for c in range(Cn):
         nb = (int(bits[c]) + 7) // 8
         assert int(offsets[c + 1] - offsets[c]) == nb and packed[int(offsets[c]): int(offsets[c]) + nb].tobytes() == out[c, :nb].tobytes(), c
+    # and back through the packed decode entry (fixed count, then variable)
+    good = err == 0
+    y, derr = ctx.decode_packed_host(packed, offsets, np.where(good, bits, 0).astype(np.uint64), T, adaptive=1)
+    assert (derr[good] == 0).all() and (y[:, good] == x[:, good]).all()
+    y2, counts, derr2 = ctx.decode_packed_host(packed, offsets, np.where(good, bits, 0).astype(np.uint64), T + 5, adaptive=1, var=True)
+    assert (derr2[good] == 0).all() and (counts[good] == T).all() and (y2[:T, good] == x[:, good]).all()
     # a buffer that is too small: the size needed is reported
     small, off2, _, _ = None, np.zeros(Cn + 1, dtype=np.uint64), None, None
     b2 = np.zeros(Cn, dtype=np.uint64)
