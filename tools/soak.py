@@ -101,6 +101,51 @@ while time.time() < t_end:
             if derr[c] != r or (r == 0 and (int(counts[c]) != len(want) or (y[: len(want), c].view(np.uint32) != want).any())):
                 bad += 1
                 print("DECODE MISMATCH", dict(vs=vs, ad=ad, C=Cn, T=T, c=int(c), hurt=bool(hurt[c]), want=r, got=int(derr[c])), flush=True)
+    # valuesize 33..64 (int64 containers), one round in six
+    if not WIDE and rounds % 6 == 0:
+        vs64 = int(rng.choice([33, 40, 48, 63, 64]))
+        T6, C6 = int(rng.choice([1, 9, 60, 200])), int(rng.choice([2, 64, 130]))
+        top6 = (1 << vs64) - 1
+        x6 = np.zeros((T6, C6), dtype=np.uint64)
+        for c in range(C6):
+            k6 = c % 3
+            if k6 == 0:
+                col = [int(v) for v in np.clip(np.cumsum(rng.integers(-5000, 5001, T6)) + 10**7, 0, None)]
+            elif k6 == 1:
+                col = [int(rng.integers(0, 2**62)) * 4 % (top6 + 1) for _ in range(T6)]
+            else:
+                col = [(top6 // 5) + int(rng.integers(0, 2**20)) for _ in range(T6)]
+            x6[:, c] = np.array(col, dtype=np.uint64)
+        o6, b6, e6 = ctx.encode64_host(np.ascontiguousarray(x6.view(np.int64)), vs64, adaptive=ad)
+        y6, n6, d6 = ctx.decode64_var_host(o6, np.where(e6 == 0, b6, 0).astype(np.uint64), T6 + 2, vs64, adaptive=ad)
+        for c in range(min(C6, 12)):
+            dd, nn = pack_be(x6[:, c], vs64)
+            r = 0
+            for name in ("diff", "seg", "bac"):
+                r, dd, nn = orc.stage(name, True, dd, nn, valuesize=vs64, adaptive=ad)
+                if r:
+                    break
+            checked += 1
+            if r != e6[c] or (r == 0 and (nn != int(b6[c]) or o6[c, : (nn + 7) // 8].tobytes() != dd[: (nn + 7) // 8])):
+                bad += 1
+                print("ENCODE64 MISMATCH", dict(vs=vs64, ad=ad, c=c, T=T6), flush=True)
+            elif r == 0:
+                r2, back, bn = 0, dd, nn
+                for name in ("bac", "seg", "diff"):
+                    r2, back, bn = orc.stage(name, False, back, bn, valuesize=vs64, adaptive=ad)
+                    if r2:
+                        break
+                if r2 != d6[c]:
+                    bad += 1
+                    print("DECODE64 STATUS MISMATCH", dict(vs=vs64, ad=ad, c=c, want=r2, got=int(d6[c])), flush=True)
+                elif r2 == 0:
+                    bits_ = np.unpackbits(np.frombuffer(back, dtype=np.uint8))[:bn].reshape(-1, vs64).astype(np.uint64)
+                    want = np.zeros(bits_.shape[0], dtype=np.uint64)
+                    for k in range(vs64):
+                        want |= bits_[:, k] << np.uint64(vs64 - 1 - k)
+                    if int(n6[c]) != len(want) or (y6[: len(want), c].view(np.uint64) != want).any():
+                        bad += 1
+                        print("DECODE64 MISMATCH", dict(vs=vs64, ad=ad, c=c), flush=True)
     # LZMH on random strings
     strings = []
     for i in range(0 if WIDE else int(rng.choice([1, 5, 70]))):
