@@ -926,7 +926,7 @@ extern "C" int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_t
   const size_t cap = dega_hip_worst_case_bytes(T);
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
     return ret;
-  if (offsets == nullptr)
+  if (offsets == nullptr || out_bits == nullptr || err == nullptr || (packed == nullptr && packed_cap != 0))
     return DEGA_ERROR_INVALID_VALUE;
   offsets[0] = 0;
   if (C == 0)
@@ -961,10 +961,12 @@ extern "C" int dega_hip_decode_packed_host(dega_hip_ctx *ctx, const uint8_t *pac
                                            size_t ld, int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
 {
   int ret;
-  if (ctx == nullptr || offsets == nullptr)
+  if (ctx == nullptr || offsets == nullptr || in_bits == nullptr || x_tc == nullptr || err == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
   if (C == 0)
     return DEGA_OK;
+  if (packed == nullptr && offsets[C] != 0)
+    return DEGA_ERROR_INVALID_VALUE;
   uint64_t longest = 0;
   for (size_t c = 0; c < C; c++)
   {
