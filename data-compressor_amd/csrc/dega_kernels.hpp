@@ -461,7 +461,10 @@ template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, bool W64 = fa
 __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + (W64 ? 2 : 1) * (DEC_SRING + 1)) * 64; // + a spare sample slot
+  // decoded samples a lane may run ahead of the slowest lane of its wave before it has to wait for the row writer: the
+  // 4-wave shape has the LDS for 64 (151 KiB per workgroup; 16 -> 64 is -5 % time), the others stay at 16
+  constexpr uint32_t SRING = NW == 4 && !W64 ? 64 : DEC_SRING;
+  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + (W64 ? 2 : 1) * (SRING + 1)) * 64; // + a spare sample slot
   __shared__ uint32_t lds[TAB_WORDS + NW * PER_WAVE];
   uint32_t *const tab = lds;
   load_div_table<ADAPTIVE>(tab, a.div_magic);
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
   uint32_t *const iring = wave_lds + lane;                               // staged stream words
   uint32_t *const stage_wave = wave_lds + DEC_IRING * 64;                // DMA landing rows (wave uniform)
   uint32_t *const sring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded samples
-  uint32_t *const sring_hi = sring + (DEC_SRING + 1) * 64;               // their high dwords (W64 only)
+  uint32_t *const sring_hi = sring + (SRING + 1) * 64;               // their high dwords (W64 only)
 
   const uint32_t cap_words = (uint32_t)(a.cap / 4);
   const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
@@ -618,9 +621,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       {
         auto take = [&]() {
           uint32_t sample;
-          const bool allowed = !lane_final && t_lane - rows_stored < DEC_SRING && t_lane < a.T;
+          const bool allowed = !lane_final && t_lane - rows_stored < SRING && t_lane < a.T;
           const bool took = sp.template take_short<NARROW>(allowed, sample);
-          sring[(took ? (uint32_t)(t_lane % DEC_SRING) : DEC_SRING) * 64u] = sample;
+          sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
           t_lane += took ? 1u : 0u;
           return took;
         };
@@ -638,12 +641,12 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       }
       // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;
       //     entered only by lanes that cannot simply wait for more bits
-      bool stalled = lane_final || t_lane - rows_stored >= DEC_SRING || !(bac_done || sp.cnt >= 32u || sp.pending());
+      bool stalled = lane_final || t_lane - rows_stored >= SRING || !(bac_done || sp.cnt >= 32u || sp.pending());
       while (wave_any(!stalled))
       {
         if (!stalled)
         {
-          if (t_lane - rows_stored >= DEC_SRING)
+          if (t_lane - rows_stored >= SRING)
             stalled = true; // sample ring full until rows are written
           else
           {
@@ -664,9 +667,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
               }
               else
               {
-                sring[(t_lane % DEC_SRING) * 64u] = (uint32_t)sample;
+                sring[(t_lane % SRING) * 64u] = (uint32_t)sample;
                 if constexpr (W64)
-                  sring_hi[(t_lane % DEC_SRING) * 64u] = (uint32_t)((uint64_t)sample >> 32);
+                  sring_hi[(t_lane % SRING) * 64u] = (uint32_t)((uint64_t)sample >> 32);
                 t_lane++;
               }
             }
@@ -701,9 +704,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++)
       {
-        cand[k] = sring[((rows_stored + k) % DEC_SRING) * 64u];
+        cand[k] = sring[((rows_stored + k) % SRING) * 64u];
         if constexpr (W64)
-          cand_hi[k] = sring_hi[((rows_stored + k) % DEC_SRING) * 64u];
+          cand_hi[k] = sring_hi[((rows_stored + k) % SRING) * 64u];
       }
       uint32_t wrote = 0;
 #pragma unroll
