@@ -2,7 +2,11 @@
 """bench.py -- DEGA encode throughput on MI355X (BASELINE.json metric: Msamples/s DEGA encode (int32)).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
+GPU; RANK / LOCAL_RANK / WORLD_SIZE come from the environment and WORLD_SIZE must equal N), or started plainly, in
+which case this process spawns the N ranks itself BEFORE anything touches a GPU and exits with their status.  Fewer than
+N visible GPUs is an error, never a silent 1-GPU measurement.
 
 A "step" is one pass of the hot path (diff -> seg -> bac adaptive, fused in one HIP kernel) over one batch of
 synthetic meter channels that is already resident in HBM: BASELINE.json configs[1], 65 536 channels x 86 400 int32
@@ -10,13 +14,15 @@ samples per GPU, [T][C] layout (22.6 GB), generated on the device
 = N disjoint channel ranges, no data-path collective ("scaling": "weak": per-GPU work is fixed).
 
 One JSON line on rank 0: throughput, the roofline of the encode kernel (HBM; algorithmic bytes = 4 B read per sample +
-the stream bytes written, over the kernel's hipEvent time on its own stream) and the CPU baseline (the reference
-itself, oracle/_ref, when it was built -- else our C port of it -- timed single threaded on a bounded sample of the
-same channels, whose GPU streams are also compared bit for bit).
-"""
+the stream bytes written, over the kernel's hipEvent time on its own stream; beside it the instruction-issue bound the
+kernel actually runs against), the CPU baseline (the reference itself, oracle/_ref, when it was built -- else our C
+port of it -- timed single threaded on a bounded sample of the same channels, whose GPU streams are also compared bit
+for bit), the PCIe-inclusive host-pointer path (`end_to_end`), and -- after the timed region, N = 1 only -- `extra`:
+the other BASELINE configs at full size (cfg3 short series, cfg4 LZMH, one GPU's share of cfg5)."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +31,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+# The model behind roofline.issue_bound_ms: VALU instructions of the unrolled symbol step (ISA count of the
+# shipped kernel, csrc/Makefile `asm`), cycles per wave instruction on a SIMD that holds one wave
+# (profiles/r01_ubench_issue_cost.txt) and the shader clock under this load.
+ISSUE_INSTR_PER_SYMBOL = 29
+ISSUE_CYCLES_PER_INSTR = 4.3
+SHADER_CLOCK_HZ = 2.25e9
 
 
 def _cpu_encode_columns(job):
@@ -85,54 +97,155 @@ def cpu_baseline(x_sample, gpu_out, gpu_bits, adaptive=1):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--channels", type=int, default=65536, help="channels per GPU")
-    ap.add_argument("--samples", type=int, default=86400, help="samples per channel")
-    ap.add_argument("--step-size", type=int, default=50, help="S of the synthetic random walk")
-    ap.add_argument("--cap-bytes-per-sample", type=float, default=4.0, help="slab bytes per sample per channel")
-    ap.add_argument("--cpu-channels", type=int, default=256, help="channels of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-round-trip", action="store_true", help="skip the decode + compare after the timed region")
-    ap.add_argument("--no-all-cores", action="store_true", help="skip the process-parallel CPU baseline")
-    ap.add_argument("--end-to-end-channels", type=int, default=8192,
-                    help="channels of the host-pointer (PCIe-inclusive) measurement after the timed region (0 = skip)")
-    ap.add_argument("--lzmh-input", choices=("ascii", "raw"), default="ascii",
-                    help="lzmh workload: the channels as ASCII '%%d.%%02d\\n' lines (the codec's domain) or as raw big-endian int32 bytes")
-    ap.add_argument("--workload", choices=("dega", "lzmh", "roundtrip"), default="dega",
-                    help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH; "
-                         "roundtrip = one GPU's share of configs[4]: --channels streamed in batches of --batch-channels, encode + decode + compare")
-    ap.add_argument("--batch-channels", type=int, default=131072, help="roundtrip workload: channels per batch (x + slabs + decoded samples must fit HBM)")
-    args = ap.parse_args()
-    if args.workload == "lzmh":
-        return main_lzmh(args)
-    if args.workload == "roundtrip":
-        return main_roundtrip(args)
-
+def seg_symbols_per_sample(x_sample):
+    """Coded symbols (= seg bits) per sample of a few channels: what the coder's serial chain is made of."""
     import numpy as np
+    from oracle import orc
+    tot = 0
+    n = min(8, x_sample.shape[1])
+    for c in range(n):
+        col = np.ascontiguousarray(x_sample[:, c]).astype(">i4").tobytes()
+        r, d, nb = orc.stage("diff", True, col, 32 * x_sample.shape[0])
+        r, d, nb = orc.stage("seg", True, d, nb)
+        tot += nb
+    return tot / float(n * x_sample.shape[0])
+
+
+class Env:
+    """Rank, device and library handles of this process."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from __graft_entry__ import load_package
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong GPU count" % (args.gpus, self.world))
+        if torch.cuda.device_count() <= self.local_rank:
+            sys.exit("bench.py: rank %d wants GPU %d but only %d are visible" % (self.rank, self.local_rank, torch.cuda.device_count()))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dca = load_package()
+        self.ctx = self.dca.Context(self.local_rank)  # raises (ERROR_LIBRARY_INIT) without a GPU: no fallback
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce_max(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        self.ctx.close()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, before this process touches a GPU."""
+    if "WORLD_SIZE" in os.environ or args.gpus == 1:
+        return
+    import socket
     import torch
-    import torch.distributed as dist
-    from __graft_entry__ import load_package
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    pool, ncores = None, 0
-    if world == 1 and args.cpu_channels > 0 and not args.no_all_cores:
-        # worker processes for the all-core CPU baseline are forked here, before anything touches the GPU
-        import multiprocessing as mp
-        ncores = min(len(os.sched_getaffinity(0)), 16)  # this GPU's share of the host
-        pool = mp.get_context("fork").Pool(ncores)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    dca = load_package()
-    ctx = dca.Context(local_rank)  # raises (ERROR_LIBRARY_INIT) without a GPU: no fallback
+def end_to_end(env, args, x, bits_dev):
+    """The host-pointer entry points of the C ABI (what a reference caller gets through the plugin): upload, kernels and
+    download pipelined over chunks of channels.  Never the headline value.  Two shapes of the same 2.8 GB of samples: the
+    headline's channel length (8 192 channels x 86 400: no chunk can finish before a whole channel's serial chain has
+    run, ~80 ms, so this shape is bounded by the kernel) and the same bytes as more, shorter channels (65 536 x 10 800:
+    bounded by the PCIe link)."""
+    import numpy as np
+    torch, ctx, dca = env.torch, env.ctx, env.dca
+    T = x.shape[0]
+    n = min(args.end_to_end_channels, x.shape[1])
+    res = {"unit": "Msamples/s", "what": "dega_hip_encode_job_host: chunks of channels on their own streams, H2D + encode + pack + D2H of the stream bytes overlapped; "
+                                         "buffers owned by the context (the first call grows them and is not timed)"}
+    # the link itself, for scale: one pinned 1 GiB copy each way
+    pin = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(1 << 30, dtype=torch.uint8, device=env.dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dbuf.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = (1 << 30) / (time.perf_counter() - t0) / 1e9
+    t0 = time.perf_counter()
+    pin.copy_(dbuf, non_blocking=True)
+    torch.cuda.synchronize()
+    d2h = (1 << 30) / (time.perf_counter() - t0) / 1e9
+    res["pcie_pinned_h2d_gbs"], res["pcie_pinned_d2h_gbs"] = round(h2d, 1), round(d2h, 1)
+    del pin, dbuf
+
+    def measure(xh_pageable, tag, check_bits):
+        Tn, Cn = xh_pageable.shape
+        out = {}
+        pinned = dca.PinnedArray((Tn, Cn), np.int32)
+        pinned.array[:] = xh_pageable
+        packed_buf = dca.PinnedArray((Cn * (Tn * 2 + 64),), np.uint8)
+        page_buf = np.zeros(Cn * (Tn * 2 + 64), dtype=np.uint8)  # touched: no first-use page faults inside the timing
+        for name, src, dst in (("pageable", xh_pageable, page_buf), ("pinned", pinned.array, packed_buf.array)):
+            ctx.encode_job(src, adaptive=1, packed=dst)  # grows the context's buffers
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                pk, off, b, e = ctx.encode_job(src, adaptive=1, packed=dst)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out[name + "_value"] = round(Cn * Tn / best / 1e6, 2)
+            out[name + "_seconds"] = round(best, 4)
+            out[name + "_h2d_gbs_equivalent"] = round(4.0 * Cn * Tn / best / 1e9, 1)
+            if check_bits is not None:
+                out["streams_equal_device_resident"] = bool(out.get("streams_equal_device_resident", True) and (b.astype(np.int64) == check_bits).all() and (e == 0).all())
+        # and back: packed streams in, samples out
+        t0 = time.perf_counter()
+        back, derr = ctx.decode_job(pk, off, b, Tn, adaptive=1, out=pinned.array)
+        t0 = time.perf_counter()
+        back, derr = ctx.decode_job(pk, off, b, Tn, adaptive=1, out=pinned.array)
+        dt = time.perf_counter() - t0
+        out["decode_pinned_value"] = round(Cn * Tn / dt / 1e6, 2)
+        out["decode_round_trip_ok"] = bool((derr == 0).all() and (back == xh_pageable).all())
+        pinned.free()
+        packed_buf.free()
+        res[tag] = out
+
+    xh = np.ascontiguousarray(x[:, :n].cpu().numpy())
+    measure(xh, "channels_%d_x_%d" % (n, T), bits_dev[:n].cpu().numpy())
+    # the same bytes as 8x the channels of 1/8 the length (a different, equally valid batch of the workload)
+    if T % 8 == 0 and n * 8 <= 65536:
+        xs = np.ascontiguousarray(xh.reshape(8, T // 8, n).transpose(1, 0, 2).reshape(T // 8, 8 * n))
+        measure(xs, "channels_%d_x_%d" % (8 * n, T // 8), None)
+    first = res["channels_%d_x_%d" % (n, T)]
+    res["value"], res["packed_value"], res["channels"] = first["pageable_value"], first["pinned_value"], n
+    return res
+
+
+def run_dega(env, args):
+    import numpy as np
+    torch, ctx = env.torch, env.ctx
+    world, rank, dev = env.world, env.rank, env.dev
     C_, T = args.channels, args.samples
     cap = 4 * int((T * args.cap_bytes_per_sample + 67) // 4)
 
@@ -143,27 +256,18 @@ def main():
     err = torch.zeros(C_, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         ctx.encode(x, adaptive=1, cap=cap, out=out, bits=bits, err=err)
-    barrier()
+    env.barrier()
     ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.encode(x, adaptive=1, cap=cap, out=out, bits=bits, err=err)
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
     n_launch, kernel_ms = ctx.profile_read(0)
-
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
+    elapsed = env.reduce_max([elapsed])[0]
 
     # bit-exact round trip at full size (the size-independent property of the metric): decode every stream on the
     # device and compare with the input on the device
@@ -177,10 +281,8 @@ def main():
         ctx.profile(False)
         _, dec_ms = ctx.profile_read(1)
         ok = bool((y == x).all().item()) and int((derr != 0).sum().item()) == 0
-        flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
-        if world > 1:
-            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-        round_trip = {"bit_exact": bool(flags.item()), "decode_kernel_ms": round(dec_ms, 3),
+        bad = env.reduce_max([0.0 if ok else 1.0])[0]
+        round_trip = {"bit_exact": bad == 0.0, "decode_kernel_ms": round(dec_ms, 3),
                       "decode_msamples_per_s_per_gpu": round(C_ * T / (dec_ms * 1e-3) / 1e6, 1) if dec_ms > 0 else None}
         del y
 
@@ -188,7 +290,7 @@ def main():
     out_bytes = int(((bits + 7) // 8).sum().item())
     algo_bytes = 4.0 * C_ * T + out_bytes  # 4 B read per sample + compressed bytes written, per launch
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-
+    res = None
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc runs, if recorded
@@ -230,52 +332,28 @@ def main():
             xs = x[:, :n].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(xs, out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
             res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-            if pool is not None:
-                res["cpu_all_cores"] = cpu_all_cores(pool, ncores, xs)
+            # what the kernel really runs against: every channel is a serial chain of coded symbols, one wave per SIMD
+            # issues one instruction per ~4.3 cycles, so a launch cannot finish before the longest chain has been issued
+            sym = seg_symbols_per_sample(xs)
+            issue_ms = T * sym * ISSUE_INSTR_PER_SYMBOL * ISSUE_CYCLES_PER_INSTR / SHADER_CLOCK_HZ * 1e3
+            res["roofline"].update({"issue_bound_ms": round(issue_ms, 2), "issue_bound_frac": round(issue_ms / kernel_ms, 4) if kernel_ms > 0 else None,
+                                    "issue_bound_model": "%d samples x %.2f coded symbols x %d VALU instructions x %.1f cycles / %.2f GHz, one wave per SIMD"
+                                                         % (T, sym, ISSUE_INSTR_PER_SYMBOL, ISSUE_CYCLES_PER_INSTR, SHADER_CLOCK_HZ / 1e9)})
+            if env.pool is not None:
+                res["cpu_all_cores"] = cpu_all_cores(env.pool, env.ncores, xs)
         if world == 1 and args.end_to_end_channels > 0:
-            # the host-pointer entry point of the C ABI: allocation + H2D + kernel + D2H, never the headline value
-            n = min(args.end_to_end_channels, C_)
-            xh = np.ascontiguousarray(x[:, :n].cpu().numpy())
-            t0 = time.perf_counter()
-            ho, hb, he = ctx.encode_host(xh, adaptive=1, cap=cap)
-            dt = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            pk, poff, pb, pe = ctx.encode_packed_host(xh, adaptive=1)
-            dtp = time.perf_counter() - t0
-            res["end_to_end"] = {"value": round(n * T / dt / 1e6, 2), "unit": "Msamples/s", "channels": n, "seconds": round(dt, 3),
-                                 "what": "dega_hip_encode_host: device alloc + H2D of pageable memory + kernel + D2H of the slabs",
-                                 "packed_value": round(n * T / dtp / 1e6, 2), "packed_seconds": round(dtp, 3),
-                                 "packed_what": "dega_hip_encode_packed_host: the same with the streams compacted on the device before D2H",
-                                 "streams_equal_device_resident": bool((hb.astype(np.int64) == bits[:n].cpu().numpy()).all()
-                                                                       and (pb.astype(np.int64) == bits[:n].cpu().numpy()).all())}
-        print(json.dumps(res), flush=True)
-    if pool is not None:
-        pool.close()
-        pool.join()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+            res["end_to_end"] = end_to_end(env, args, x, bits)
+    del x, out, bits, err
+    torch.cuda.empty_cache()
+    return res
 
 
-def main_roundtrip(args):
+def run_roundtrip(env, args):
     """One GPU's share of BASELINE configs[4] (8 Mi channels x 86 400 samples over 8 GPUs = 1 Mi channels per GPU, 362 GB
     of samples: more than HBM holds): the rank's channel range streamed in batches -- generate on the device, encode,
     decode, compare with the input -- one step = the whole range.  No data leaves the GPU; no collective."""
-    import torch
-    import torch.distributed as dist
-    from __graft_entry__ import load_package
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dca = load_package()
-    ctx = dca.Context(local_rank)
+    torch, ctx = env.torch, env.ctx
+    world, rank, dev = env.world, env.rank, env.dev
     C_, T, B = args.channels, args.samples, min(args.batch_channels, args.channels)
     cap = 4 * int((T * args.cap_bytes_per_sample + 67) // 4)
     x = torch.empty((T, B), dtype=torch.int32, device=dev)
@@ -307,25 +385,18 @@ def main_roundtrip(args):
                 out_bytes += int(((bits[:n] + 7) // 8).sum().item())
         return ok, enc_ms, dec_ms, out_bytes
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         one_pass(False)
-    barrier()
+    env.barrier()
     t0 = time.perf_counter()
     ok, enc_ms, dec_ms, out_bytes = True, 0.0, 0.0, 0
     for _ in range(args.steps):
         o, e, d, ob = one_pass(True)
         ok, enc_ms, dec_ms, out_bytes = ok and o, enc_ms + e, dec_ms + d, ob
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
-    vals = torch.tensor([elapsed, enc_ms, dec_ms, 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-    elapsed, enc_ms, dec_ms, bad = [float(v) for v in vals.tolist()]
+    elapsed, enc_ms, dec_ms, bad = env.reduce_max([elapsed, enc_ms, dec_ms, 0.0 if ok else 1.0])
+    res = None
     if rank == 0:
         kernel_s = (enc_ms + dec_ms) * 1e-3
         algo = 2.0 * (4.0 * C_ * T + out_bytes)  # encode: samples in + stream out; decode: the reverse
@@ -343,11 +414,9 @@ def main_roundtrip(args):
                          "encode_ms_per_step": round(enc_ms / args.steps, 3), "decode_ms_per_step": round(dec_ms / args.steps, 3)},
             "round_trip": {"bit_exact": bad == 0.0},
         }
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    del x, y, out, bits, err, derr
+    torch.cuda.empty_cache()
+    return res
 
 
 def lzmh_cpu_baseline(texts, gpu_out, gpu_bits):
@@ -372,23 +441,11 @@ def lzmh_cpu_baseline(texts, gpu_out, gpu_bits):
             "gpu_streams_bit_exact": mismatches == 0}
 
 
-def main_lzmh(args):
+def run_lzmh(env, args):
     """BASELINE configs[3]: LZMH encode of the cfg2 channels rendered as ASCII "%d.%02d\\n" lines, one GPU
     lane per channel.  Same contract as the DEGA line; the unit is bytes of text."""
-    import torch
-    import torch.distributed as dist
-    from __graft_entry__ import load_package
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dca = load_package()
-    ctx = dca.Context(local_rank)
+    torch, ctx = env.torch, env.ctx
+    world, rank, dev = env.world, env.rank, env.dev
     C_, T = args.channels, args.samples
     x = torch.empty((T, C_), dtype=torch.int32, device=dev)
     ctx.synth(C_, T, seed=1234, c0=rank * C_, S=args.step_size, out=x)
@@ -414,30 +471,22 @@ def main_lzmh(args):
     bits = torch.zeros(C_, dtype=torch.int64, device=dev)
     err = torch.zeros(C_, dtype=torch.int32, device=dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         ctx.lzmh_encode(text, lens, cap=cap, out=out, bits=bits, err=err)
-    barrier()
+    env.barrier()
     ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.lzmh_encode(text, lens, cap=cap, out=out, bits=bits, err=err)
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
     ctx.profile(False)
     n_launch, kernel_ms = ctx.profile_read(2)
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
+    elapsed = env.reduce_max([elapsed])[0]
     in_bytes = int(lens.sum().item())
     tot = torch.tensor([in_bytes], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        env.dist.all_reduce(tot, op=env.dist.ReduceOp.SUM)
     total_bytes = int(tot.item())
 
     round_trip = None
@@ -453,16 +502,15 @@ def main_lzmh(args):
             sl = slice(c0, min(C_, c0 + 8192))
             idx = torch.arange(stride, device=dev)[None, :] < lens[sl, None]
             ok = ok and bool(((back[sl] == text[sl]) | ~idx).all().item())
-        flags = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
-        if world > 1:
-            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-        round_trip = {"bit_exact": bool(flags.item()), "decode_kernel_ms": round(dec_ms, 3),
+        bad = env.reduce_max([0.0 if ok else 1.0])[0]
+        round_trip = {"bit_exact": bad == 0.0, "decode_kernel_ms": round(dec_ms, 3),
                       "decode_mb_per_s_per_gpu": round(in_bytes / (dec_ms * 1e-3) / 1e6, 1) if dec_ms > 0 else None}
         del back
 
     out_bytes = int(((bits + 7) // 8).sum().item())
     algo_bytes = float(in_bytes + out_bytes)  # every text byte read once + the stream bytes written
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    res = None
     if rank == 0:
         res = {
             "metric": "MB/s LZMH encode (%s)" % ("ASCII lines" if args.lzmh_input == "ascii" else "raw int32 bytes"), "value": round(total_bytes * args.steps / elapsed / 1e6, 2), "unit": "MB/s",
@@ -489,11 +537,82 @@ def main_lzmh(args):
             texts = [tc[c, : int(lc[c])].tobytes() for c in range(n)]
             res["cpu_baseline"] = lzmh_cpu_baseline(texts, out[:n].cpu().numpy(), bits[:n].cpu().numpy())
             res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+    del text, lens, out, bits, err
+    torch.cuda.empty_cache()
+    return res
+
+
+def extras(env, args):
+    """The other BASELINE configs at full size, after the timed region (N = 1): sub-records with their own roofline."""
+    out = {}
+    a = argparse.Namespace(**vars(args))
+    # configs[2]: 1 Mi channels x 96 samples (15-min data, S = 300): encode with its round trip
+    a.channels, a.samples, a.step_size, a.steps, a.warmup, a.cpu_channels, a.end_to_end_channels, a.no_round_trip = 1048576, 96, 300, 5, 1, 0, 0, False
+    r = run_dega(env, a)
+    out["cfg3"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip")}
+    # configs[3]: LZMH of the cfg2 channels as ASCII lines, 39.4 GB of text, with the reference's `encode lzmh` beside it
+    a = argparse.Namespace(**vars(args))
+    a.channels, a.samples, a.step_size, a.steps, a.warmup, a.cpu_channels, a.lzmh_input, a.no_round_trip = 65536, 86400, 50, 2, 1, 128, "ascii", False
+    r = run_lzmh(env, a)
+    out["cfg4_lzmh"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip", "cpu_baseline", "gpu_over_cpu") if k in r}
+    # configs[4]: one GPU's share (1 Mi channels x 86 400), streamed in batches, encode + decode + compare on the device
+    a = argparse.Namespace(**vars(args))
+    a.channels, a.samples, a.step_size, a.steps, a.warmup, a.batch_channels = 1048576, 86400, 50, 1, 0, 131072
+    r = run_roundtrip(env, a)
+    out["cfg5_share"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip")}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--channels", type=int, default=65536, help="channels per GPU")
+    ap.add_argument("--samples", type=int, default=86400, help="samples per channel")
+    ap.add_argument("--step-size", type=int, default=50, help="S of the synthetic random walk")
+    ap.add_argument("--cap-bytes-per-sample", type=float, default=4.0, help="slab bytes per sample per channel")
+    ap.add_argument("--cpu-channels", type=int, default=256, help="channels of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-round-trip", action="store_true", help="skip the decode + compare after the timed region")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the process-parallel CPU baseline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg3 / cfg4 / cfg5-share sub-records after the timed region")
+    ap.add_argument("--end-to-end-channels", type=int, default=8192,
+                    help="channels of the host-pointer (PCIe-inclusive) measurement after the timed region (0 = skip)")
+    ap.add_argument("--lzmh-input", choices=("ascii", "raw"), default="ascii",
+                    help="lzmh workload: the channels as ASCII '%%d.%%02d\\n' lines (the codec's domain) or as raw big-endian int32 bytes")
+    ap.add_argument("--workload", choices=("dega", "lzmh", "roundtrip"), default="dega",
+                    help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH; "
+                         "roundtrip = one GPU's share of configs[4]: --channels streamed in batches of --batch-channels, encode + decode + compare")
+    ap.add_argument("--batch-channels", type=int, default=131072, help="roundtrip workload: channels per batch (x + slabs + decoded samples must fit HBM)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be at least 1")
+    spawn_ranks_if_needed(args)  # does not return in the launching process
+
+    pool, ncores = None, 0
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "dega" and args.cpu_channels > 0 and not args.no_all_cores:
+        # worker processes for the all-core CPU baseline are forked here, before anything touches the GPU
+        import multiprocessing as mp
+        ncores = min(len(os.sched_getaffinity(0)), 16)  # this GPU's share of the host
+        pool = mp.get_context("fork").Pool(ncores)
+    env = Env(args)
+    env.pool, env.ncores = pool, ncores
+    if args.workload == "lzmh":
+        res = run_lzmh(env, args)
+    elif args.workload == "roundtrip":
+        res = run_roundtrip(env, args)
+    else:
+        res = run_dega(env, args)
+        default_shape = (args.channels, args.samples, args.step_size) == (65536, 86400, 50)
+        if res is not None and env.world == 1 and default_shape and not args.no_extras:
+            res["extra"] = extras(env, args)
+    if env.rank == 0:
+        assert res["n_gpus"] == args.gpus
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    if pool is not None:
+        pool.close()
+        pool.join()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -65,9 +65,31 @@ _SIGNATURES = {
     "dega_hip_lzmh_render_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, _P, _Z, _P, _P, _P]),
     "dega_hip_lzmh_encode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P]),
     "dega_hip_lzmh_decode_host": (C.c_int, [_P, _P, _Z, _P, _Z, _P, _Z, _P, _P]),
+    "dega_hip_encode_f32_dev": (C.c_int, [_P, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _Z, _P, _P, _P]),
+    "dega_hip_decode_f32_dev": (C.c_int, [_P, _P, _Z, _P, _Z, _Z, _Z, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dega_hip_encode_job_host": (C.c_int, [_P, _P, _P, _P, _Z, _P, _P, _P]),
+    "dega_hip_decode_job_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "dega_hip_split_channels": (C.c_int, [_Z, C.c_int, _P]),
+    "dega_hip_group_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "dega_hip_group_destroy": (None, [_P]),
+    "dega_hip_group_size": (C.c_int, [_P]),
+    "dega_hip_group_context": (_P, [_P, C.c_int]),
+    "dega_hip_group_last_error": (C.c_char_p, [_P]),
+    "dega_hip_group_encode": (C.c_int, [_P, _P, _P, _P, _Z, _P, _P, _P]),
+    "dega_hip_group_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "dega_hip_pinned_alloc": (_P, [_Z]),
+    "dega_hip_pinned_free": (None, [_P]),
     "dega_hip_profile": (C.c_int, [_P, C.c_int]),
     "dega_hip_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_int]),
 }
+
+SAMPLES_I32, SAMPLES_BE32, SAMPLES_I64, SAMPLES_F32 = 0, 1, 2, 3
+
+
+class Job(C.Structure):
+    """dega_hip_job of include/dega_hip.h"""
+    _fields_ = [("C", _Z), ("T", _Z), ("ld", _Z), ("adaptive", C.c_int), ("valuesize", C.c_int), ("samples", C.c_int), ("factor", C.c_float)]
+
 
 _lib = None
 
@@ -109,8 +131,130 @@ def lzmh_worst_case_bytes(n):
     return library().dega_hip_lzmh_worst_case_bytes(n)
 
 
-class Context:
+def _sample_dtype(samples):
+    import numpy as np
+    return {SAMPLES_I32: np.dtype(np.int32), SAMPLES_BE32: np.dtype(">i4"), SAMPLES_I64: np.dtype(np.int64), SAMPLES_F32: np.dtype(np.float32)}[samples]
+
+
+class _JobCalls:
+    """encode_job / decode_job on numpy arrays: the packed host-pointer surface, shared by Context (one device) and Group
+    (every device).  Subclasses provide _enc_fn / _dec_fn / _handle / _check."""
+
+    def encode_job(self, x_tc, adaptive=1, valuesize=32, samples=SAMPLES_I32, factor=100.0, packed_cap=None, channels=None, packed=None):
+        """x_tc: [T, ld] array of the sample type (channels = the first `channels` columns, default all).
+        Returns (packed uint8 [total], offsets uint64 [C+1], bits uint64 [C], err int32 [C])."""
+        import numpy as np
+        if not (isinstance(x_tc, np.ndarray) and x_tc.flags.c_contiguous and x_tc.dtype == _sample_dtype(samples)):
+            x_tc = np.ascontiguousarray(x_tc, dtype=_sample_dtype(samples))
+        T, pitch = x_tc.shape
+        Cn = pitch if channels is None else int(channels)
+        job = Job(Cn, T, pitch, int(adaptive), int(valuesize), int(samples), float(factor))
+        if packed_cap is None:
+            packed_cap = Cn * (T * 2 + 64)  # generous for meter data; the call says so if it is not
+        offsets = np.zeros(Cn + 1, dtype=np.uint64)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = OK
+        for _ in range(2):
+            buf = packed if packed is not None and packed.size >= packed_cap else np.empty(max(1, packed_cap), dtype=np.uint8)
+            ret = self._enc_fn()(self._handle(), C.byref(job), x_tc.ctypes.data, buf.ctypes.data, packed_cap, offsets.ctypes.data, bits.ctypes.data, err.ctypes.data)
+            if ret != ERROR_MEMORY or int(offsets[Cn]) <= packed_cap:
+                break
+            packed_cap = int(offsets[Cn])
+        self._check(ret, "encode_job")
+        return buf[: int(offsets[Cn])], offsets, bits, err
+
+    def decode_job(self, packed, offsets, bits, T, adaptive=1, valuesize=32, samples=SAMPLES_I32, factor=100.0, var=False, out=None):
+        """The inverse.  Returns (x [T, C] of the sample type, err) or, with var=True, (x, counts, err)."""
+        import numpy as np
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn = bits.size
+        x = out if out is not None else np.zeros((T, Cn), dtype=_sample_dtype(samples))
+        counts = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        job = Job(Cn, T, x.shape[1] if x.ndim == 2 else Cn, int(adaptive), int(valuesize), int(samples), float(factor))
+        ret = self._dec_fn()(self._handle(), C.byref(job), packed.ctypes.data, offsets.ctypes.data, bits.ctypes.data, x.ctypes.data,
+                             counts.ctypes.data if var else None, err.ctypes.data)
+        self._check(ret, "decode_job")
+        return (x, counts, err) if var else (x, err)
+
+
+class PinnedArray:
+    """numpy view of pinned host memory (dega_hip_pinned_alloc): `.array`; `.free()` when done."""
+
+    def __init__(self, shape, dtype):
+        import numpy as np
+        count = int(np.prod(shape))
+        n = max(1, count * np.dtype(dtype).itemsize)
+        self._p = library().dega_hip_pinned_alloc(n)
+        if not self._p:
+            raise DegaError(ERROR_MEMORY, "dega_hip_pinned_alloc(%d)" % n)
+        self._buf = (C.c_uint8 * n).from_address(self._p)
+        self.array = np.frombuffer(self._buf, dtype=dtype, count=count).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            self._buf = None
+            library().dega_hip_pinned_free(self._p)
+            self._p = None
+
+
+class Group(_JobCalls):
+    """dega_hip_group: every visible GPU (or `devices`), channel ranges per device, host-side concatenate."""
+
+    def __init__(self, devices=None):
+        self._h = _P()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            ret = library().dega_hip_group_create(arr, len(devices), C.byref(self._h))
+        else:
+            ret = library().dega_hip_group_create(None, 0, C.byref(self._h))
+        if ret != OK:
+            self._h = None
+            raise DegaError(ret, "dega_hip_group_create")
+
+    def size(self):
+        return library().dega_hip_group_size(self._h)
+
+    def close(self):
+        if self._h:
+            library().dega_hip_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        return self._h
+
+    def _enc_fn(self):
+        return library().dega_hip_group_encode
+
+    def _dec_fn(self):
+        return library().dega_hip_group_decode
+
+    def _check(self, ret, what):
+        if ret != OK:
+            raise DegaError(ret, "%s [%s]" % (what, library().dega_hip_group_last_error(self._h).decode()))
+
+
+class Context(_JobCalls):
     """One device context (dega_hip_ctx).  Methods take torch CUDA tensors and enqueue on torch's current stream."""
+
+    def _handle(self):
+        return self._h
+
+    def _enc_fn(self):
+        return library().dega_hip_encode_job_host
+
+    def _dec_fn(self):
+        return library().dega_hip_decode_job_host
 
     def __init__(self, device=0):
         self._h = _P()
@@ -175,6 +319,31 @@ class Context:
                                             x_tc.data_ptr(), err.data_ptr(), self._stream())
         self._check(ret, "dega_hip_decode_dev")
         return x_tc, err
+
+    def encode_f32(self, v_tc, factor=100.0, adaptive=1, cap=None, valuesize=32):
+        """float32 CUDA tensor [T, C] -> streams: Normalize fused into the encode kernel (one launch)."""
+        import torch
+        T, Cn = v_tc.shape
+        assert v_tc.dtype == torch.float32 and v_tc.is_cuda and v_tc.is_contiguous()
+        if cap is None:
+            cap = worst_case_bytes(T) if valuesize <= 32 else library().dega_hip_worst_case_bytes64(T)
+        out = torch.zeros((Cn, cap), dtype=torch.uint8, device=v_tc.device)
+        bits = torch.zeros(Cn, dtype=torch.int64, device=v_tc.device)
+        err = torch.zeros(Cn, dtype=torch.int32, device=v_tc.device)
+        ret = library().dega_hip_encode_f32_dev(self._h, v_tc.data_ptr(), Cn, T, Cn, float(factor), int(adaptive), int(valuesize), out.data_ptr(), cap,
+                                                bits.data_ptr(), err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_encode_f32_dev")
+        return out, bits, err
+
+    def decode_f32(self, streams, bits, T, factor=100.0, adaptive=1, valuesize=32):
+        import torch
+        Cn, cap = streams.shape
+        v = torch.zeros((T, Cn), dtype=torch.float32, device=streams.device)
+        err = torch.zeros(Cn, dtype=torch.int32, device=streams.device)
+        ret = library().dega_hip_decode_f32_dev(self._h, streams.data_ptr(), cap, bits.data_ptr(), Cn, T, Cn, float(factor), int(adaptive), int(valuesize),
+                                                v.data_ptr(), None, err.data_ptr(), self._stream())
+        self._check(ret, "dega_hip_decode_f32_dev")
+        return v, err
 
     def normalize(self, v_tc, factor=100.0, valuesize=32):
         import torch
@@ -411,7 +580,7 @@ class Context:
         v_tc = np.ascontiguousarray(v_tc, dtype=np.float32)
         T, Cn = v_tc.shape
         if cap is None:
-            cap = worst_case_bytes(T)
+            cap = worst_case_bytes(T) if valuesize <= 32 else library().dega_hip_worst_case_bytes64(T)
         out = np.zeros((Cn, cap), dtype=np.uint8)
         bits = np.zeros(Cn, dtype=np.uint64)
         err = np.zeros(Cn, dtype=np.int32)

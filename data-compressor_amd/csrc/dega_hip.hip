@@ -1,7 +1,9 @@
 // dega_hip.hip -- host side of libdega_hip.so: the C ABI declared in include/dega_hip.h.
 //
-// Owns one context per device (division table in HBM, scratch buffers for the host-pointer entry points, optional
-// hipEvent timing of the hot kernels) and launches the kernels of dega_kernels.hpp.  Built for gfx950 only:
+// One context per device: the division table in HBM, pooled hipEvents for the optional kernel timing, and -- for the
+// host-pointer entry points -- a pipeline of streams with grow-only device and pinned-host buffers (dega_pipeline.hpp).
+// A group (dega_hip_group) is a set of contexts, one host thread per device, channel ranges per device, host-side
+// concatenation of the packed streams; no collective.  Built for gfx950 only:
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC dega_hip.hip -o libdega_hip.so      (see csrc/Makefile)
 #include <hip/hip_runtime.h>
 
@@ -12,10 +14,19 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace dg;
+
+struct Pipeline;
+static void pipeline_destroy(Pipeline *p);
 
 struct dega_hip_ctx
 {
@@ -24,8 +35,9 @@ struct dega_hip_ctx
   char last_error[256];
   bool profile;
   std::vector<hipEvent_t> ev[4]; // start/stop pairs per kernel kind (0 encode, 1 decode, 2 lzmh encode, 3 lzmh decode)
-  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_pool; // events handed back by profile_read, reused by the next timed launches
   int force_waves; // 0 = choose by batch size; 4 / 8 = DEGA_WAVES_PER_WORKGROUP (measurement knob)
+  Pipeline *pipe;  // streams and buffers of the host-pointer entry points, created on first use
 };
 
 static int fail(dega_hip_ctx *ctx, int code, const char *what, hipError_t e)
@@ -66,7 +78,7 @@ extern "C" int dega_hip_device_count(void)
 
 extern "C" const char *dega_hip_version(void)
 {
-  return "dega-hip 0.1 (gfx950)";
+  return "dega-hip 0.2 (gfx950)";
 }
 
 extern "C" size_t dega_hip_worst_case_bytes(size_t T)
@@ -97,6 +109,7 @@ extern "C" int dega_hip_create(int device, dega_hip_ctx **out)
   ctx->div_magic = nullptr;
   ctx->last_error[0] = '\0';
   ctx->profile = false;
+  ctx->pipe = nullptr;
   {
     const char *w = getenv("DEGA_WAVES_PER_WORKGROUP");
     const int v = w != nullptr ? atoi(w) : 0;
@@ -129,9 +142,13 @@ extern "C" void dega_hip_destroy(dega_hip_ctx *ctx)
   if (ctx == nullptr)
     return;
   (void)hipSetDevice(ctx->device);
-  for (int k = 0; k < 2; k++)
+  (void)hipDeviceSynchronize();
+  pipeline_destroy(ctx->pipe);
+  for (int k = 0; k < 4; k++)
     for (hipEvent_t e : ctx->ev[k])
       (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_pool)
+    (void)hipEventDestroy(e);
   (void)hipFree(ctx->div_magic);
   delete ctx;
 }
@@ -153,6 +170,7 @@ extern "C" int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_m
 {
   if (ctx == nullptr || which < 0 || which > 3 || avg_ms == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
+  (void)hipSetDevice(ctx->device);
   std::vector<hipEvent_t> &v = ctx->ev[which];
   double sum = 0.0;
   int n = 0;
@@ -168,53 +186,63 @@ extern "C" int dega_hip_profile_read(dega_hip_ctx *ctx, int which, double *avg_m
   *avg_ms = n ? sum / n : 0.0;
   if (reset)
   {
-    for (hipEvent_t e : v)
-      (void)hipEventDestroy(e);
+    ctx->ev_pool.insert(ctx->ev_pool.end(), v.begin(), v.end()); // kept for the next timed launches
     v.clear();
   }
   return n;
 }
 
-// RAII-free helper: brackets a launch with events on the launch's own stream when profiling is on
+// Brackets a launch with events on the launch's own stream when profiling is on.  Events come from the context's pool;
+// a context never holds more than DEGA_MAX_TIMED launches' worth (later launches go untimed until profile_read resets).
+constexpr size_t DEGA_MAX_TIMED = 4096;
 struct LaunchTimer
 {
   dega_hip_ctx *ctx;
   int which;
   hipStream_t s;
-  LaunchTimer(dega_hip_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st)
+  bool armed;
+  static bool take(dega_hip_ctx *ctx, hipEvent_t *e)
   {
-    if (ctx->profile)
+    if (!ctx->ev_pool.empty())
     {
-      hipEvent_t e;
-      if (hipEventCreate(&e) == hipSuccess)
-      {
-        (void)hipEventRecord(e, s);
-        ctx->ev[which].push_back(e);
-      }
+      *e = ctx->ev_pool.back();
+      ctx->ev_pool.pop_back();
+      return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+  }
+  LaunchTimer(dega_hip_ctx *c, int w, hipStream_t st) : ctx(c), which(w), s(st), armed(false)
+  {
+    hipEvent_t e;
+    if (ctx->profile && ctx->ev[which].size() < 2 * DEGA_MAX_TIMED && take(ctx, &e))
+    {
+      (void)hipEventRecord(e, s);
+      ctx->ev[which].push_back(e);
+      armed = true;
     }
   }
   ~LaunchTimer()
   {
-    if (ctx->profile && (ctx->ev[which].size() & 1u))
+    if (!armed)
+      return;
+    hipEvent_t e;
+    if (take(ctx, &e))
     {
-      hipEvent_t e;
-      if (hipEventCreate(&e) == hipSuccess)
-      {
-        (void)hipEventRecord(e, s);
-        ctx->ev[which].push_back(e);
-      }
-      else
-      {
-        (void)hipEventDestroy(ctx->ev[which].back());
-        ctx->ev[which].pop_back();
-      }
+      (void)hipEventRecord(e, s);
+      ctx->ev[which].push_back(e);
+    }
+    else
+    {
+      ctx->ev_pool.push_back(ctx->ev[which].back());
+      ctx->ev[which].pop_back();
     }
   }
 };
 
+constexpr size_t DEGA_MAX_T = (size_t)1 << 25; // samples per channel and call: T * 65 seg bits are counted in 32 bits
+
 static int check_shape(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t cap, int valuesize)
 {
-  (void)T;
   if (ctx == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
   if (valuesize < 1 || valuesize > 32)
@@ -223,10 +251,196 @@ static int check_shape(dega_hip_ctx *ctx, size_t C, size_t T, size_t ld, size_t 
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "ld < C", hipSuccess);
   if (cap % 4 != 0 || cap > ((size_t)1 << 29))
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "cap must be a multiple of 4 and at most 512 MiB", hipSuccess);
-  if (T > ((size_t)1 << 25))
+  if (T > DEGA_MAX_T)
     return fail(ctx, DEGA_ERROR_INVALID_VALUE, "at most 2^25 samples per channel and call", hipSuccess);
   return DEGA_OK;
 }
+
+// ---- kernel dispatch ---------------------------------------------------------------------------------------------------
+// One batch: its size and what its samples are (include/dega_hip.h: DEGA_SAMPLES_*)
+struct Shape
+{
+  size_t C, T, ld;
+  int adaptive, valuesize, samples;
+  float factor;
+};
+
+static int check_job_shape(dega_hip_ctx *ctx, const Shape &j, size_t cap)
+{
+  if (ctx == nullptr)
+    return DEGA_ERROR_INVALID_VALUE;
+  const bool wide = j.valuesize > 32;
+  if (j.samples < DEGA_SAMPLES_I32 || j.samples > DEGA_SAMPLES_F32 || j.valuesize < 1 || j.valuesize > 64 ||
+      ((j.samples == DEGA_SAMPLES_I32 || j.samples == DEGA_SAMPLES_BE32) && wide) || (j.samples == DEGA_SAMPLES_I64 && !wide))
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "sample type and valuesize do not go together (int32 / big-endian: 1..32, int64: 33..64, float32: 1..64)",
+                hipSuccess);
+  return check_shape(ctx, j.C, j.T, j.ld, cap, 32);
+}
+
+template <bool AD, bool NARROW, bool F32>
+static void encode_launch(bool eight_waves, size_t C, hipStream_t s, const EncodeArgs &a)
+{
+  if (eight_waves) // more than one wave per SIMD of work: 8-wave workgroups with smaller rings, two waves per SIMD
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 8, 4, 16, 24, false, F32>), dim3((unsigned)((C + 511) / 512)), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, WAVES, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, s, a);
+}
+
+// `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
+static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_t batch_C, uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err,
+                         hipStream_t s)
+{
+  int ret;
+  if ((ret = check_job_shape(ctx, j, cap)) != DEGA_OK)
+    return ret;
+  if (j.C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  const int vs = j.valuesize;
+  EncodeArgs a;
+  a.x = reinterpret_cast<const int32_t *>(x);
+  a.C = j.C;
+  a.T = j.T;
+  a.ld = j.ld;
+  a.out = out;
+  a.cap = cap;
+  a.out_bits = out_bits;
+  a.err = err;
+  a.div_magic = ctx->div_magic;
+  a.valuesize = (uint32_t)vs;
+  a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
+  a.factor = j.factor;
+  // the bounds of normalize.c:21, rounded to float by the host compiler exactly as the reference's are
+  a.lo = -(float)((uint64_t)1 << (vs - 1));
+  a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);
+  const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
+  const bool eight = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
+  {
+    LaunchTimer lt(ctx, 0, s);
+    if (vs > 32) // 64-bit values: one shape
+    {
+      const dim3 grid((unsigned)((j.C + BLOCK - 1) / BLOCK));
+      if (f32)
+      {
+        if (ad)
+          hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true, true>), grid, dim3(BLOCK), 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true, true>), grid, dim3(BLOCK), 0, s, a);
+      }
+      else if (ad)
+        hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true, false>), grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true, false>), grid, dim3(BLOCK), 0, s, a);
+    }
+    else
+    {
+      const bool narrow = vs < 32; // the narrow variants mask the samples and range check against the value size
+      const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
+      switch (sel)
+      {
+        case 0: encode_launch<false, false, false>(eight, j.C, s, a); break;
+        case 1: encode_launch<false, false, true>(eight, j.C, s, a); break;
+        case 2: encode_launch<false, true, false>(eight, j.C, s, a); break;
+        case 3: encode_launch<false, true, true>(eight, j.C, s, a); break;
+        case 4: encode_launch<true, false, false>(eight, j.C, s, a); break;
+        case 5: encode_launch<true, false, true>(eight, j.C, s, a); break;
+        case 6: encode_launch<true, true, false>(eight, j.C, s, a); break;
+        default: encode_launch<true, true, true>(eight, j.C, s, a); break;
+      }
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+template <bool AD, bool NARROW, bool F32>
+static void decode_launch(bool eight_waves, size_t C, hipStream_t s, const DecodeArgs &a)
+{
+  if (eight_waves)
+    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, 8, false, F32>), dim3((unsigned)((C + 511) / 512)), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, WAVES, false, F32>), dim3((unsigned)((C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+}
+
+static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, const Shape &j, size_t batch_C, void *x,
+                         uint64_t *out_count, int32_t *err, hipStream_t s)
+{
+  int ret;
+  if ((ret = check_job_shape(ctx, j, cap)) != DEGA_OK)
+    return ret;
+  if (j.C == 0)
+    return DEGA_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  const int vs = j.valuesize;
+  DecodeArgs a;
+  a.in = in;
+  a.cap = cap;
+  a.in_bits = in_bits;
+  a.C = j.C;
+  a.T = j.T;
+  a.ld = j.ld;
+  a.x = reinterpret_cast<int32_t *>(x);
+  a.err = err;
+  a.div_magic = ctx->div_magic;
+  a.out_count = out_count;
+  a.valuesize = (uint32_t)vs;
+  a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
+  a.factor = j.factor;
+  const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
+  const bool eight = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
+  {
+    LaunchTimer lt(ctx, 1, s);
+    if (vs > 32)
+    {
+      const dim3 grid((unsigned)((j.C + BLOCK - 1) / BLOCK));
+      if (f32)
+      {
+        if (ad)
+          hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true, true>), grid, dim3(BLOCK), 0, s, a);
+        else
+          hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true, true>), grid, dim3(BLOCK), 0, s, a);
+      }
+      else if (ad)
+        hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true, false>), grid, dim3(BLOCK), 0, s, a);
+      else
+        hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true, false>), grid, dim3(BLOCK), 0, s, a);
+    }
+    else
+    {
+      const bool narrow = vs < 32;
+      const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
+      switch (sel)
+      {
+        case 0: decode_launch<false, false, false>(eight, j.C, s, a); break;
+        case 1: decode_launch<false, false, true>(eight, j.C, s, a); break;
+        case 2: decode_launch<false, true, false>(eight, j.C, s, a); break;
+        case 3: decode_launch<false, true, true>(eight, j.C, s, a); break;
+        case 4: decode_launch<true, false, false>(eight, j.C, s, a); break;
+        case 5: decode_launch<true, false, true>(eight, j.C, s, a); break;
+        case 6: decode_launch<true, true, false>(eight, j.C, s, a); break;
+        default: decode_launch<true, true, true>(eight, j.C, s, a); break;
+      }
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+  return DEGA_OK;
+}
+
+static Shape shape_of(size_t C, size_t T, size_t ld, int adaptive, int valuesize, int samples, float factor = 0.0f)
+{
+  Shape j;
+  j.C = C;
+  j.T = T;
+  j.ld = ld;
+  j.adaptive = adaptive;
+  j.valuesize = valuesize;
+  j.samples = samples;
+  j.factor = factor;
+  return j;
+}
+
+// ---- device-pointer entry points ---------------------------------------------------------------------------------------
 
 extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                                    uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream)
@@ -234,129 +448,39 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   int ret;
   if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
     return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  EncodeArgs a;
-  a.x = x_tc;
-  a.C = C;
-  a.T = T;
-  a.ld = ld;
-  a.out = out;
-  a.cap = cap;
-  a.out_bits = out_bits;
-  a.err = err;
-  a.div_magic = ctx->div_magic;
-  a.valuesize = (uint32_t)valuesize;
-  hipStream_t s = (hipStream_t)stream;
-  {
-    LaunchTimer lt(ctx, 0, s);
-    if (ctx->force_waves == 8 || (ctx->force_waves == 0 && C > 65536)) // more than one wave per SIMD of work: 8-wave workgroups with smaller rings, two waves per SIMD
-    {
-      const dim3 grid((unsigned)((C + 511) / 512)), block(512);
-      if (valuesize < 32)
-      {
-        if (adaptive)
-          hipLaunchKernelGGL((dega_encode_kernel<true, true, 8, 4, 16, 24>), grid, block, 0, s, a);
-        else
-          hipLaunchKernelGGL((dega_encode_kernel<false, true, 8, 4, 16, 24>), grid, block, 0, s, a);
-      }
-      else if (adaptive)
-        hipLaunchKernelGGL((dega_encode_kernel<true, false, 8, 4, 16, 24>), grid, block, 0, s, a);
-      else
-        hipLaunchKernelGGL((dega_encode_kernel<false, false, 8, 4, 16, 24>), grid, block, 0, s, a);
-    }
-    else
-    {
-      const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-      if (valuesize < 32) // the narrow variants mask the samples and range check against the value size
-      {
-        if (adaptive)
-          hipLaunchKernelGGL((dega_encode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
-        else
-          hipLaunchKernelGGL((dega_encode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
-      }
-      else if (adaptive)
-        hipLaunchKernelGGL(dega_encode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
-      else
-        hipLaunchKernelGGL(dega_encode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
-    }
-  }
-  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                         int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
-{
-  int ret;
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DecodeArgs a;
-  a.in = in;
-  a.cap = cap;
-  a.in_bits = in_bits;
-  a.C = C;
-  a.T = T;
-  a.ld = ld;
-  a.x = x_tc;
-  a.err = err;
-  a.div_magic = ctx->div_magic;
-  a.out_count = out_count;
-  a.valuesize = (uint32_t)valuesize;
-  hipStream_t s = (hipStream_t)stream;
-  {
-    LaunchTimer lt(ctx, 1, s);
-    if (ctx->force_waves == 8 || (ctx->force_waves == 0 && C > 65536)) // more than one wave per SIMD of work: 8-wave workgroups, two waves per SIMD
-    {
-      const dim3 grid((unsigned)((C + 511) / 512)), block(512);
-      if (valuesize < 32)
-      {
-        if (adaptive)
-          hipLaunchKernelGGL((dega_decode_kernel<true, true, 8>), grid, block, 0, s, a);
-        else
-          hipLaunchKernelGGL((dega_decode_kernel<false, true, 8>), grid, block, 0, s, a);
-      }
-      else if (adaptive)
-        hipLaunchKernelGGL((dega_decode_kernel<true, false, 8>), grid, block, 0, s, a);
-      else
-        hipLaunchKernelGGL((dega_decode_kernel<false, false, 8>), grid, block, 0, s, a);
-    }
-    else
-    {
-      const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-      if (valuesize < 32)
-      {
-        if (adaptive)
-          hipLaunchKernelGGL((dega_decode_kernel<true, true>), grid, dim3(BLOCK), 0, s, a);
-        else
-          hipLaunchKernelGGL((dega_decode_kernel<false, true>), grid, dim3(BLOCK), 0, s, a);
-      }
-      else if (adaptive)
-        hipLaunchKernelGGL(dega_decode_kernel<true>, grid, dim3(BLOCK), 0, s, a);
-      else
-        hipLaunchKernelGGL(dega_decode_kernel<false>, grid, dim3(BLOCK), 0, s, a);
-    }
-  }
-  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
+  return launch_encode(ctx, x_tc, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_I32), C, out, cap, out_bits, err, (hipStream_t)stream);
 }
 
 extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                    int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
 {
-  return launch_decode(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err, stream);
+  int ret;
+  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  return launch_decode(ctx, in, cap, in_bits, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_I32), C, x_tc, nullptr, err, (hipStream_t)stream);
 }
 
 extern "C" int dega_hip_decode_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
                                        int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
 {
+  int ret;
   if (out_count == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
-  return launch_decode(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err, stream);
+  if ((ret = check_shape(ctx, C, max_T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  return launch_decode(ctx, in, cap, in_bits, shape_of(C, max_T, ld, adaptive, valuesize, DEGA_SAMPLES_I32), C, x_tc, out_count, err, (hipStream_t)stream);
+}
+
+extern "C" int dega_hip_encode_f32_dev(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
+                                       uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream)
+{
+  return launch_encode(ctx, v_tc, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_F32, factor), C, out, cap, out_bits, err, (hipStream_t)stream);
+}
+
+extern "C" int dega_hip_decode_f32_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                                       float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err, void *stream)
+{
+  return launch_decode(ctx, in, cap, in_bits, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_F32, factor), C, v_tc, out_count, err, (hipStream_t)stream);
 }
 
 static dim3 rowsplit_grid(size_t C, size_t T)
@@ -491,79 +615,27 @@ extern "C" int dega_hip_encode64_dev(dega_hip_ctx *ctx, const int64_t *x_tc, siz
   int ret;
   if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
     return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  EncodeArgs a;
-  a.x = reinterpret_cast<const int32_t *>(x_tc);
-  a.C = C;
-  a.T = T;
-  a.ld = ld;
-  a.out = out;
-  a.cap = cap;
-  a.out_bits = out_bits;
-  a.err = err;
-  a.div_magic = ctx->div_magic;
-  a.valuesize = (uint32_t)valuesize;
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-  hipStream_t s = (hipStream_t)stream;
-  {
-    LaunchTimer lt(ctx, 0, s);
-    if (adaptive)
-      hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true>), grid, dim3(BLOCK), 0, s, a);
-    else
-      hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true>), grid, dim3(BLOCK), 0, s, a);
-  }
-  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-static int launch_decode64(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                           int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
-{
-  int ret;
-  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DecodeArgs a;
-  a.in = in;
-  a.cap = cap;
-  a.in_bits = in_bits;
-  a.C = C;
-  a.T = T;
-  a.ld = ld;
-  a.x = reinterpret_cast<int32_t *>(x_tc);
-  a.err = err;
-  a.div_magic = ctx->div_magic;
-  a.out_count = out_count;
-  a.valuesize = (uint32_t)valuesize;
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
-  hipStream_t s = (hipStream_t)stream;
-  {
-    LaunchTimer lt(ctx, 1, s);
-    if (adaptive)
-      hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true>), grid, dim3(BLOCK), 0, s, a);
-    else
-      hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true>), grid, dim3(BLOCK), 0, s, a);
-  }
-  HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
+  return launch_encode(ctx, x_tc, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_I64), C, out, cap, out_bits, err, (hipStream_t)stream);
 }
 
 extern "C" int dega_hip_decode64_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                      int adaptive, int valuesize, int64_t *x_tc, int32_t *err, void *stream)
 {
-  return launch_decode64(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err, stream);
+  int ret;
+  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  return launch_decode(ctx, in, cap, in_bits, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_I64), C, x_tc, nullptr, err, (hipStream_t)stream);
 }
 
 extern "C" int dega_hip_decode64_var_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
                                          int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err, void *stream)
 {
+  int ret;
   if (out_count == nullptr)
     return DEGA_ERROR_INVALID_VALUE;
-  return launch_decode64(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err, stream);
+  if ((ret = check_shape64(ctx, C, max_T, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  return launch_decode(ctx, in, cap, in_bits, shape_of(C, max_T, ld, adaptive, valuesize, DEGA_SAMPLES_I64), C, x_tc, out_count, err, (hipStream_t)stream);
 }
 
 // ---- LZMH (BASELINE config 4) ----------------------------------------------------------------------------------------
@@ -635,375 +707,5 @@ extern "C" int dega_hip_lzmh_render_dev(dega_hip_ctx *ctx, const int32_t *x_tc, 
   return DEGA_OK;
 }
 
-// ---- host-pointer entry points ---------------------------------------------------------------------------------------
-
-struct DevBuf
-{
-  void *p = nullptr;
-  ~DevBuf()
-  {
-    if (p != nullptr)
-      (void)hipFree(p);
-  }
-  hipError_t alloc(size_t n)
-  {
-    return hipMalloc(&p, n > 0 ? n : 1);
-  }
-};
-
-extern "C" int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
-                                    uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
-{
-  int ret;
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dx, dout, dbits, derr;
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-static int decode_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                            int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
-
-extern "C" int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                                    int adaptive, int valuesize, int32_t *x_tc, int32_t *err)
-{
-  return decode_host_impl(ctx, in, cap, in_bits, C, T, ld, adaptive, valuesize, x_tc, nullptr, err);
-}
-
-extern "C" int dega_hip_decode_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
-                                        int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
-{
-  if (out_count == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  return decode_host_impl(ctx, in, cap, in_bits, C, max_T, ld, adaptive, valuesize, x_tc, out_count, err);
-}
-
-static int decode_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                            int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
-{
-  int ret;
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dx, din, dbits, derr;
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dcount;
-  if (out_count != nullptr)
-    HIP_TRY(ctx, dcount.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  if ((ret = launch_decode(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
-                           out_count != nullptr ? (uint64_t *)dcount.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, T * ld * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  if (out_count != nullptr)
-    HIP_TRY(ctx, hipMemcpy(out_count, dcount.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
-                                        uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
-{
-  int ret;
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dv, dx, dout, dbits, derr, dnerr;
-  HIP_TRY(ctx, dv.alloc(T * ld * sizeof(float)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dnerr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(dv.p, v_tc, T * ld * sizeof(float), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_normalize_dev(ctx, (const float *)dv.p, C, T, ld, factor, valuesize, (int32_t *)dx.p, (int32_t *)dnerr.p, nullptr)) != DEGA_OK)
-    return ret;
-  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  std::vector<int32_t> nerr(C);
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(nerr.data(), dnerr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  for (size_t c = 0; c < C; c++) // the first failing stage of the chain reports (normalize runs before diff)
-    if (nerr[c] != DEGA_OK)
-      err[c] = nerr[c];
-  return DEGA_OK;
-}
-
-static int decode_f32_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                                float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err);
-
-extern "C" int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                                        float factor, int adaptive, int valuesize, float *v_tc, int32_t *err)
-{
-  return decode_f32_host_impl(ctx, in, cap, in_bits, C, T, ld, factor, adaptive, valuesize, v_tc, nullptr, err);
-}
-
-extern "C" int dega_hip_decode_f32_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
-                                            float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err)
-{
-  if (out_count == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  return decode_f32_host_impl(ctx, in, cap, in_bits, C, max_T, ld, factor, adaptive, valuesize, v_tc, out_count, err);
-}
-
-static int decode_f32_host_impl(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
-                                float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err)
-{
-  int ret;
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dv, dx, din, dbits, derr;
-  HIP_TRY(ctx, dv.alloc(T * ld * sizeof(float)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dcount;
-  if (out_count != nullptr)
-    HIP_TRY(ctx, dcount.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  if ((ret = launch_decode(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
-                           out_count != nullptr ? (uint64_t *)dcount.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  if (out_count != nullptr)
-    HIP_TRY(ctx, hipMemcpy(out_count, dcount.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_denormalize_dev(ctx, (const int32_t *)dx.p, C, T, ld, factor, valuesize, (float *)dv.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(v_tc, dv.p, T * ld * sizeof(float), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_lzmh_encode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out,
-                                         size_t cap, uint64_t *out_bits, int32_t *err)
-{
-  if (ctx == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf din, dlen, dout, dbits, derr;
-  HIP_TRY(ctx, din.alloc(C * stride), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dlen.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(din.p, in, C * stride, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dlen.p, in_len, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
-  int ret;
-  if ((ret = dega_hip_lzmh_encode_dev(ctx, (const uint8_t *)din.p, stride, (const uint64_t *)dlen.p, C, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p,
-                                      (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out,
-                                         size_t stride, uint64_t *out_len, int32_t *err)
-{
-  if (ctx == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf din, dbits, dout, dlen, derr;
-  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * stride), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dlen.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  int ret;
-  if ((ret = dega_hip_lzmh_decode_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, (uint8_t *)dout.p, stride, (uint64_t *)dlen.p,
-                                      (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * stride, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_len, dlen.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_encode64_host(dega_hip_ctx *ctx, const int64_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
-                                      uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err)
-{
-  int ret;
-  if ((ret = check_shape64(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dx, dout, dbits, derr;
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dout.p, 0, C * cap), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_encode64_dev(ctx, (const int64_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out, dout.p, C * cap, hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_decode64_var_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t max_T, size_t ld,
-                                          int adaptive, int valuesize, int64_t *x_tc, uint64_t *out_count, int32_t *err)
-{
-  int ret;
-  if (out_count == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  if ((ret = check_shape64(ctx, C, max_T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf din, dbits, dx, dcnt, derr;
-  HIP_TRY(ctx, din.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dx.alloc(max_T * ld * sizeof(int64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dcnt.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(din.p, in, C * cap, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dx.p, 0, max_T * ld * sizeof(int64_t)), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_decode64_var_dev(ctx, (const uint8_t *)din.p, cap, (const uint64_t *)dbits.p, C, max_T, ld, adaptive, valuesize, (int64_t *)dx.p,
-                                       (uint64_t *)dcnt.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, max_T * ld * sizeof(int64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_count, dcnt.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
-                                           uint8_t *packed, size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err)
-{
-  int ret;
-  const size_t cap = dega_hip_worst_case_bytes(T);
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  if (offsets == nullptr || out_bits == nullptr || err == nullptr || (packed == nullptr && packed_cap != 0))
-    return DEGA_ERROR_INVALID_VALUE;
-  offsets[0] = 0;
-  if (C == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  DevBuf dx, dout, dbits, derr, doff, dpacked;
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dout.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, doff.alloc((C + 1) * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, hipMemcpy(dx.p, x_tc, T * ld * sizeof(int32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  if ((ret = dega_hip_encode_dev(ctx, (const int32_t *)dx.p, C, T, ld, adaptive, valuesize, (uint8_t *)dout.p, cap, (uint64_t *)dbits.p, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  if ((ret = dega_hip_compact_offsets_dev(ctx, (const uint64_t *)dbits.p, C, (uint64_t *)doff.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipMemcpy(offsets, doff.p, (C + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(out_bits, dbits.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  if (offsets[C] > packed_cap)
-    return fail(ctx, DEGA_ERROR_MEMORY, "packed buffer too small: offsets[C] holds the size needed", hipSuccess);
-  if (offsets[C] == 0)
-    return DEGA_OK;
-  HIP_TRY(ctx, dpacked.alloc((size_t)offsets[C]), DEGA_ERROR_MEMORY);
-  if ((ret = dega_hip_compact_gather_dev(ctx, (const uint8_t *)dout.p, cap, (const uint64_t *)doff.p, C, (uint8_t *)dpacked.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipMemcpy(packed, dpacked.p, (size_t)offsets[C], hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
-
-extern "C" int dega_hip_decode_packed_host(dega_hip_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, size_t T,
-                                           size_t ld, int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err)
-{
-  int ret;
-  if (ctx == nullptr || offsets == nullptr || in_bits == nullptr || x_tc == nullptr || err == nullptr)
-    return DEGA_ERROR_INVALID_VALUE;
-  if (C == 0)
-    return DEGA_OK;
-  if (packed == nullptr && offsets[C] != 0)
-    return DEGA_ERROR_INVALID_VALUE;
-  uint64_t longest = 0;
-  for (size_t c = 0; c < C; c++)
-  {
-    if (offsets[c + 1] < offsets[c] || (in_bits[c] + 7) / 8 > offsets[c + 1] - offsets[c])
-      return fail(ctx, DEGA_ERROR_INVALID_VALUE, "offsets must grow and hold ceil(bits / 8) bytes per channel", hipSuccess);
-    longest = offsets[c + 1] - offsets[c] > longest ? offsets[c + 1] - offsets[c] : longest;
-  }
-  const size_t cap = ((size_t)longest + 16 + 3) & ~(size_t)3; // room for the decoder's word look-ahead
-  if ((ret = check_shape(ctx, C, T, ld, cap, valuesize)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
-  const size_t total = (size_t)offsets[C];
-  DevBuf dpacked, doff, dslabs, dbits, dx, dcnt, derr;
-  HIP_TRY(ctx, dpacked.alloc(total), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, doff.alloc((C + 1) * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dslabs.alloc(C * cap), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dbits.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dx.alloc(T * ld * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, dcnt.alloc(C * sizeof(uint64_t)), DEGA_ERROR_MEMORY);
-  HIP_TRY(ctx, derr.alloc(C * sizeof(int32_t)), DEGA_ERROR_MEMORY);
-  if (total > 0)
-    HIP_TRY(ctx, hipMemcpy(dpacked.p, packed, total, hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(doff.p, offsets, (C + 1) * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(dbits.p, in_bits, C * sizeof(uint64_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemset(dx.p, 0, T * ld * sizeof(int32_t)), DEGA_ERROR_LIBRARY_CALL);
-  {
-    GatherArgs g{(const uint8_t *)dslabs.p, cap, (const uint64_t *)doff.p, C, (uint8_t *)dpacked.p};
-    hipLaunchKernelGGL(dega_scatter_kernel, dim3((unsigned)((C + WAVES - 1) / WAVES)), dim3(BLOCK), 0, nullptr, g);
-    HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-  }
-  if ((ret = launch_decode(ctx, (const uint8_t *)dslabs.p, cap, (const uint64_t *)dbits.p, C, T, ld, adaptive, valuesize, (int32_t *)dx.p,
-                           out_count != nullptr ? (uint64_t *)dcnt.p : nullptr, (int32_t *)derr.p, nullptr)) != DEGA_OK)
-    return ret;
-  HIP_TRY(ctx, hipDeviceSynchronize(), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(x_tc, dx.p, T * ld * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  if (out_count != nullptr)
-    HIP_TRY(ctx, hipMemcpy(out_count, dcnt.p, C * sizeof(uint64_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  HIP_TRY(ctx, hipMemcpy(err, derr.p, C * sizeof(int32_t), hipMemcpyDeviceToHost), DEGA_ERROR_LIBRARY_CALL);
-  return DEGA_OK;
-}
+// ---- host-pointer entry points: the pipeline and the multi-device group ------------------------------------------------------
+#include "dega_pipeline.hpp"

@@ -97,6 +97,72 @@ inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
 inline void wait_vector_memory() {}
 #endif
 
+// lo = -(float)2^(valuesize-1), hi = (float)(2^(valuesize-1) - 1) as the host's C compiler rounds them (normalize.c:21;
+// hi rounds up to 2^(valuesize-1) from valuesize 26 on), mask = the low valuesize bits written (normalize.c:24)
+DG_DEV bool normalize_value(float v, float factor, int32_t &out, float lo = -2147483648.0f, float hi = 2147483648.0f, uint32_t mask = 0xFFFFFFFFu)
+{
+#if defined(DEGA_SIM)
+  volatile float prod;
+  if (v > 0.0f)
+  {
+    prod = v * factor;
+    v = prod + 0.5f;
+  }
+  else if (v < 0.0f)
+  {
+    prod = v * factor;
+    v = prod - 0.5f;
+  }
+#else
+  if (v > 0.0f)
+    v = __fadd_rn(__fmul_rn(v, factor), 0.5f); // normalize.c:17-18
+  else if (v < 0.0f)
+    v = __fsub_rn(__fmul_rn(v, factor), 0.5f); // :19-20
+#endif
+  const bool ok = !(v < lo || v > hi); // :21 -- for valuesize 32 (float)(2^31-1) is 2^31, so exactly 2^31 passes
+  out = (int32_t)((v >= 2147483648.0f ? 0x80000000u : (uint32_t)(int32_t)v) & mask); // :23-24 (int64) truncation, low valuesize bits
+  return ok;
+}
+
+
+// The same for valuesize 33..64: the normalized value is an io_int_t = int64 (normalize.c:23), written as its low
+// valuesize bits.  v >= 2^63 (reachable only through the rounded upper bound at valuesize 64) converts like x86's
+// cvttss2si does: to the "integer indefinite" 0x8000000000000000.
+DG_DEV bool normalize_value64(float v, float factor, uint64_t &out, float lo, float hi, uint64_t mask)
+{
+#if defined(DEGA_SIM)
+  volatile float prod;
+  if (v > 0.0f)
+  {
+    prod = v * factor;
+    v = prod + 0.5f;
+  }
+  else if (v < 0.0f)
+  {
+    prod = v * factor;
+    v = prod - 0.5f;
+  }
+#else
+  if (v > 0.0f)
+    v = __fadd_rn(__fmul_rn(v, factor), 0.5f);
+  else if (v < 0.0f)
+    v = __fsub_rn(__fmul_rn(v, factor), 0.5f);
+#endif
+  const bool ok = !(v < lo || v > hi);
+  const bool big = v >= 9223372036854775808.0f || v < -9223372036854775808.0f || v != v;
+  out = (big ? 0x8000000000000000ull : (uint64_t)(int64_t)v) & mask;
+  return ok;
+}
+
+DG_DEV float denormalize_value(float n, float factor) // normalize.c:38: true IEEE division, no reciprocal
+{
+#if defined(DEGA_SIM)
+  return n / factor;
+#else
+  return __fdiv_rn(n, factor);
+#endif
+}
+
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
 
@@ -116,6 +182,9 @@ struct EncodeArgs
   int32_t *err;
   const uint32_t *div_magic; // DIV_TABLE_SIZE division magics (dega_lane.hpp), global memory
   uint32_t valuesize;        // 1..32: samples are the low valuesize bits of x, unsigned (diff.c:15)
+  uint32_t big_endian;       // 32-bit samples arrive byte swapped (the big-endian words `encode normalize` writes, bit_file_buffer.c:297-308)
+  // F32IN variants (normalize fused into the fill phase, normalize.c:9-27): x holds raw float32 bits
+  float factor, lo, hi;      // normalization factor; range of normalize.c:21 for the value size, rounded to float by the host compiler
 };
 
 template <bool ADAPTIVE>
@@ -137,13 +206,17 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
 // LDS (154 KiB), and the second wave of each SIMD fills the issue slots the first leaves empty while it waits.
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
 // writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated as <.., 4, 4, 32, 32, true>.
+// F32IN: the rows are float32 readings; Normalize (normalize.c:16-24) runs on each value as it leaves LDS, in front of
+// the difference -- one launch, no int32 intermediate in HBM.  With W64 the rows stay one dword per lane (floats) and
+// the normalized value is 64 bits wide (valuesize 33..64, normalize.c:21-24 with io_int_t = int64).
 template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING,
-          bool W64 = false>
+          bool W64 = false, bool F32IN = false>
 __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a)
 {
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
   constexpr uint32_t FILL_WORDS = (31 + (W64 ? 127 : 65) * ROWS) / 32; // most words a batch can add (worst-case codewords)
-  constexpr uint32_t LDS_ROWS = W64 ? 2 * ROWS : ROWS;
+  constexpr bool ROWS64 = W64 && !F32IN; // rows of two dwords per lane
+  constexpr uint32_t LDS_ROWS = ROWS64 ? 2 * ROWS : ROWS;
   static_assert(FILL_WORDS < RING && ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
   const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
@@ -188,10 +261,10 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   // When the wave's 64 channels all exist and rows are 16-byte aligned, one LDS-DMA instruction fetches FOUR rows:
   // lanes 16r .. 16r+15 read row r's 256 bytes as 16-byte pieces, which land as row r of the [row][64] LDS image.
   const size_t c_wave0 = (size_t)blockIdx.x * (NW * 64u) + wave * 64u;
-  const bool rows_x4 = !W64 && (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
+  const bool rows_x4 = !ROWS64 && (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
   auto issue_rows = [&](size_t t0) // rows [t0, t0 + ROWS), clamped to the last row
   {
-    if constexpr (W64)
+    if constexpr (ROWS64)
     {
       const int64_t *const x64 = reinterpret_cast<const int64_t *>(a.x);
 #pragma unroll
@@ -307,7 +380,14 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
           for (uint32_t i = 0; i < ROWS; i++)
             if (i < left)
             {
-              const uint64_t u = (((uint64_t)rows_col[(2u * i + 1u) * 64u] << 32) | rows_col[(2u * i) * 64u]) & vmask64;
+              uint64_t u;
+              if constexpr (F32IN)
+              {
+                if (!normalize_value64(__uint_as_float(rows_col[i * 64u]), a.factor, u, a.lo, a.hi, vmask64) && lane_err == OK)
+                  lane_err = ERR_INVALID_VALUE; // normalize.c:21-22
+              }
+              else
+                u = (((uint64_t)rows_col[(2u * i + 1u) * 64u] << 32) | rows_col[(2u * i) * 64u]) & vmask64;
               const SegWord64 sw = diff_seg64(u, last64, a.valuesize);
               if (!sw.ok && lane_err == OK)
                 lane_err = ERR_INVALID_VALUE;
@@ -320,10 +400,40 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
         uint32_t xr[ROWS];
 #pragma unroll
         for (uint32_t i = 0; i < ROWS; i++)
-          xr[i] = NARROW ? rows_col[i * 64u] & vmask : rows_col[i * 64u];
+          xr[i] = rows_col[i * 64u];
 #pragma unroll
         for (uint32_t i = 0; i < ROWS; i++)
           DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
+        if constexpr (F32IN)
+        {
+          // Normalize (normalize.c:16-24) on the way in; rows past the end of the channel repeat the last row, whose
+          // verdict is the same, so the whole batch can be checked
+          bool all_in_range = true;
+#pragma unroll
+          for (uint32_t i = 0; i < ROWS; i++)
+          {
+            int32_t n;
+            all_in_range = normalize_value(__uint_as_float(xr[i]), a.factor, n, a.lo, a.hi, vmask) && all_in_range;
+            xr[i] = (uint32_t)n;
+          }
+          if (!all_in_range && lane_err == OK)
+            lane_err = ERR_INVALID_VALUE;
+        }
+        else
+        {
+          if (a.big_endian) // wave uniform
+          {
+#pragma unroll
+            for (uint32_t i = 0; i < ROWS; i++)
+              xr[i] = bswap32(xr[i]);
+          }
+          if (NARROW)
+          {
+#pragma unroll
+            for (uint32_t i = 0; i < ROWS; i++)
+              xr[i] &= vmask;
+          }
+        }
         // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
         uint32_t w[ROWS];
         uint32_t last_try = last;
@@ -451,13 +561,17 @@ struct DecodeArgs
   const uint32_t *div_magic;
   uint64_t *out_count; // NULL: every channel must hold exactly T samples.  Else: up to T samples, count reported here
   uint32_t valuesize;  // 1..32: samples come out as the low valuesize bits, zero extended (diff.c:34)
+  uint32_t big_endian; // 32-bit samples are stored byte swapped (what `decode diff` writes: big-endian words)
+  float factor;        // F32OUT variants: Denormalize (normalize.c:29-41) fused into the row write; x is float [T][ld]
 };
 
 // NW = waves per workgroup: 4 (one per SIMD) for batches of up to 64 Ki channels, 8 for larger ones -- two waves per SIMD
 // fill the issue slots a lone wave leaves empty while it waits on LDS or memory (the LDS budget allows it: 138 KiB)
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; the parser is SegParser64 (no short-codeword passes), samples take two
 // LDS slots.  Instantiated with NW = 4.
-template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, bool W64 = false>
+// F32OUT: the decoded value, read back as valuesize bits sign extended (normalize.c:36-37), leaves as (float)n / factor
+// (:38, IEEE division) -- float32 rows [T][ld] also for W64, no integer intermediate in HBM.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, bool W64 = false, bool F32OUT = false>
 __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
@@ -715,13 +829,26 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         const size_t row = rows_stored + k;
         if (wrote == k && row < a.T && wave_all(lane_final || t_lane > row) && (a.out_count == nullptr || wave_any(t_lane > row)))
         {
-          if constexpr (W64)
+          if constexpr (F32OUT)
+          {
+            float v;
+            if constexpr (W64)
+            {
+              const uint32_t sh64 = 64u - a.valuesize; // 0..31
+              v = denormalize_value((float)((int64_t)((((uint64_t)cand_hi[k] << 32) | cand[k]) << sh64) >> sh64), a.factor);
+            }
+            else
+              v = denormalize_value((float)(NARROW ? (int32_t)(cand[k] << sp.vshift) >> sp.vshift : (int32_t)cand[k]), a.factor);
+            if (live)
+              reinterpret_cast<float *>(a.x)[row * a.ld + c] = t_lane > row ? v : 0.0f;
+          }
+          else if constexpr (W64)
           {
             if (live)
               reinterpret_cast<int64_t *>(a.x)[row * a.ld + c] = t_lane > row ? (int64_t)(((uint64_t)cand_hi[k] << 32) | cand[k]) : 0;
           }
           else if (live)
-            a.x[row * a.ld + c] = t_lane > row ? (int32_t)cand[k] : 0;
+            a.x[row * a.ld + c] = t_lane > row ? (int32_t)(a.big_endian ? bswap32(cand[k]) : cand[k]) : 0;
           wrote = k + 1;
         }
       }
@@ -761,33 +888,6 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
 // normalize / denormalize (DCLib/src/normalize.c), elementwise, HBM bound.  Float parity rules: the
 // multiply and the +-0.5 are two separately rounded operations (no FMA), truncating convert, IEEE division.
 // ---------------------------------------------------------------------------------------------------------------------
-// lo = -(float)2^(valuesize-1), hi = (float)(2^(valuesize-1) - 1) as the host's C compiler rounds them (normalize.c:21;
-// hi rounds up to 2^(valuesize-1) from valuesize 26 on), mask = the low valuesize bits written (normalize.c:24)
-DG_DEV bool normalize_value(float v, float factor, int32_t &out, float lo = -2147483648.0f, float hi = 2147483648.0f, uint32_t mask = 0xFFFFFFFFu)
-{
-#if defined(DEGA_SIM)
-  volatile float prod;
-  if (v > 0.0f)
-  {
-    prod = v * factor;
-    v = prod + 0.5f;
-  }
-  else if (v < 0.0f)
-  {
-    prod = v * factor;
-    v = prod - 0.5f;
-  }
-#else
-  if (v > 0.0f)
-    v = __fadd_rn(__fmul_rn(v, factor), 0.5f); // normalize.c:17-18
-  else if (v < 0.0f)
-    v = __fsub_rn(__fmul_rn(v, factor), 0.5f); // :19-20
-#endif
-  const bool ok = !(v < lo || v > hi); // :21 -- for valuesize 32 (float)(2^31-1) is 2^31, so exactly 2^31 passes
-  out = (int32_t)((v >= 2147483648.0f ? 0x80000000u : (uint32_t)(int32_t)v) & mask); // :23-24 (int64) truncation, low valuesize bits
-  return ok;
-}
-
 struct NormalizeArgs
 {
   const float *v;
@@ -838,11 +938,7 @@ __global__ void __launch_bounds__(256) dega_denormalize_kernel(const Denormalize
   for (size_t t = t0; t < t1; t++)
   {
     const int32_t n = (int32_t)((uint32_t)a.x[t * a.ld + c] << a.vshift) >> a.vshift;
-#if defined(DEGA_SIM)
-    a.v[t * a.ld + c] = (float)n / a.factor;
-#else
-    a.v[t * a.ld + c] = __fdiv_rn((float)n, a.factor); // normalize.c:38, true division
-#endif
+    a.v[t * a.ld + c] = denormalize_value((float)n, a.factor);
   }
 }
 

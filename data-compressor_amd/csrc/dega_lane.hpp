@@ -68,6 +68,15 @@ DG_DEV uint32_t bswap32(uint32_t x)
   return __builtin_bswap32(x);
 }
 
+#if defined(DEGA_SIM)
+inline float __uint_as_float(uint32_t u)
+{
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+#endif
+
 DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // mask is all ones or all zeros
 {
 #if defined(DEGA_SIM)

@@ -111,7 +111,7 @@ struct options_t
   size_t num_decimal_places;
   float normalization_factor;
   size_t num_values;
-  size_t num_channels; /* NOT in the reference: channels interleaved in one stream (dega / fdega only), default 1 */
+  size_t num_channels; /* NOT in the reference: channels in one stream -- interleaved samples (dega / fdega), equal pieces (glzmh); default 1 */
 };
 
 /* the table of codecs: sorted by name, looked up by bsearch with a prefix comparison (enc_dec.c:89-98) */
@@ -121,6 +121,7 @@ const enc_dec_t *GetEncoder(const char *name);
 const char *GetEncoderDescription(const char *name);
 const char *GetEncoderNameFromFunction(enc_dec_function_t *function, int encoder);
 int EncoderSupportsOption(const char *encoder_name, const char *option_name);
+int EncoderFromFunctionSupportsOption(enc_dec_function_t *function, int encoder, const char *option_name);
 /* the table of options */
 size_t GetNumberOfOptions(void);
 void GetOptionNames(const char **names);

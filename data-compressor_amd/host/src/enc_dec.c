@@ -49,7 +49,7 @@ static const codec_row_t codecs[] = { /* sorted by name */
   { "copy", "Copies input to output", { &CopyBits, &CopyBits }, OPT_BLOCKSIZE },
   { "dega", "diff + seg + bac on the GPU (MI355X), big-endian integer values in", { &EncodeDEGA, &DecodeDEGA }, OPT_ADAPTIVE | OPT_VALUESIZE | OPT_NUM_CHANNELS },
   { "fdega", "normalize + diff + seg + bac on the GPU (MI355X), raw floats in", { &EncodeDEGAFloat, &DecodeDEGAFloat }, OPT_ADAPTIVE | OPT_VALUESIZE | OPT_NORMALIZATION | OPT_NUM_CHANNELS },
-  { "glzmh", "LZMH on the GPU (MI355X): the stream of the reference's lzmh, bit for bit", { &EncodeLZMHGPU, &DecodeLZMHGPU }, 0 },
+  { "glzmh", "LZMH on the GPU (MI355X): the stream of the reference's lzmh, bit for bit", { &EncodeLZMHGPU, &DecodeLZMHGPU }, OPT_NUM_CHANNELS },
 };
 static const size_t num_codecs = sizeof(codecs) / sizeof(codecs[0]);
 
@@ -58,7 +58,7 @@ static const option_row_t option_rows[] = { /* sorted by name */
   { "blocksize", OPT_BLOCKSIZE, "Use blocks of <n> bits size for I/O", OT_SIZE, 1, SIZE_MAX, offsetof(options_t, block_size_bits) },
   { "column", OPT_COLUMN, "Use column <n>", OT_SIZE, 1, SIZE_MAX, offsetof(options_t, column) },
   { "normalization_factor", OPT_NORMALIZATION, "Use multiplier <n> for normalization and <1/n> for denormalization", OT_FLOAT, 0, SIZE_MAX, offsetof(options_t, normalization_factor) },
-  { "num_channels", OPT_NUM_CHANNELS, "Treat the input as <n> interleaved channels (one batch on the GPU)", OT_SIZE, 1, SIZE_MAX, offsetof(options_t, num_channels) },
+  { "num_channels", OPT_NUM_CHANNELS, "Treat the input as <n> channels coded as one batch on the GPU (dega / fdega: interleaved samples; glzmh: <n> equal pieces)", OT_SIZE, 1, SIZE_MAX, offsetof(options_t, num_channels) },
   { "num_decimal_places", OPT_DECIMALS, "Use <n> decimal places to print floats into CSV files", OT_SIZE, 0, 6, offsetof(options_t, num_decimal_places) },
   { "num_values", OPT_NUM_VALUES, "Use <n> values for aggregation", OT_SIZE, 0, SIZE_MAX, offsetof(options_t, num_values) },
   { "separator_char", OPT_SEPARATOR, "Use <n> as CSV entry separator", OT_CHAR, 0, CHAR_MAX, offsetof(options_t, separator_char) },
@@ -169,6 +169,18 @@ int EncoderSupportsOption(const char *encoder_name, const char *option_name)
   const codec_row_t *r = find_codec(encoder_name);
   const option_row_t *o = find_option(option_name);
   return r != NULL && o != NULL && (r->options & o->bit) == o->bit;
+}
+
+/* enc_dec.c:216-225 of the reference: the option mask of the row a codec FUNCTION belongs to (DCCLI checks options of
+   an already-resolved stage this way, DCCLI/src/cli.c:305) */
+int EncoderFromFunctionSupportsOption(enc_dec_function_t *function, int encoder, const char *option_name)
+{
+  const option_row_t *o = find_option(option_name);
+  size_t i;
+  for (i = 0; i < num_codecs; i++)
+    if ((encoder && codecs[i].functions.encoder == function) || (!encoder && codecs[i].functions.decoder == function))
+      return o != NULL && (codecs[i].options & o->bit) == o->bit;
+  return 0;
 }
 
 void SetDefaultOptions(options_t *options)

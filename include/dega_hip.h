@@ -26,7 +26,8 @@
  *            bits : uint64 [C]      exact stream length in bits (the last byte is zero padded)
  *            err  : int32 [C]       DEGA_OK or a negative reference error code for that channel
  * "dev" entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t passed as void*, NULL = default
- * stream) without synchronising.  "host" entry points take host pointers and are synchronous.
+ * stream) without synchronising.  "host" entry points take host pointers and are synchronous; inside they are a
+ * pipeline over chunks of channels, and dega_hip_group_* spreads one over every GPU of the node.
  * There is no CPU fallback: without a usable GPU every call fails with DEGA_ERROR_LIBRARY_INIT.
  */
 #ifndef DEGA_HIP_H
@@ -47,7 +48,26 @@ extern "C" {
 #define DEGA_ERROR_LIBRARY_INIT (-10)   /* no GPU / HIP runtime failure at init */
 #define DEGA_ERROR_LIBRARY_CALL (-11)   /* HIP failure during a call */
 
-typedef struct dega_hip_ctx dega_hip_ctx; /* one context = one device; not thread safe (like the reference's codecs) */
+typedef struct dega_hip_ctx dega_hip_ctx;     /* one context = one device; not thread safe (like the reference's codecs) */
+typedef struct dega_hip_group dega_hip_group; /* several contexts: one per GPU of the node, channels split between them */
+
+/* What the samples of a batch are (the `samples` field of dega_hip_job). */
+#define DEGA_SAMPLES_I32 0  /* int32 [T][ld], native byte order, valuesize 1..32 */
+#define DEGA_SAMPLES_BE32 1 /* the same as 32-bit big-endian words: what `encode normalize` writes and `decode diff` emits
+                               for valuesize 32 (DCIOLib/src/bit_file_buffer.c:297-308) -- swapped on the device, not by the caller */
+#define DEGA_SAMPLES_I64 2  /* int64 [T][ld], valuesize 33..64 */
+#define DEGA_SAMPLES_F32 3  /* float32 [T][ld] readings, valuesize 1..64: Normalize / Denormalize (DCLib/src/normalize.c:9-41)
+                               run inside the encode / decode kernel, one launch per direction */
+
+/* One batch of C channels x T samples for the host-pointer entry points. */
+typedef struct dega_hip_job
+{
+  size_t C, T, ld; /* channels, samples per channel, row pitch of `samples` in elements (>= C) */
+  int adaptive;    /* 0 = `bac`, 1 = `bac adaptive` */
+  int valuesize;   /* the `valuesize` option of the stages, 1..64 */
+  int samples;     /* DEGA_SAMPLES_* */
+  float factor;    /* normalization_factor (DEGA_SAMPLES_F32 only) */
+} dega_hip_job;
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------------- */
 int dega_hip_device_count(void);                            /* number of visible GPUs, 0 if none / no runtime */
@@ -136,7 +156,55 @@ int dega_hip_lzmh_encode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t strid
 int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride,
                               uint64_t *out_len, int32_t *err);
 
-/* ---- host-pointer convenience (H2D, kernels, D2H; synchronous) ---------------------------------------------------- */
+/* ---- float entry / exit fused into the coder kernels, device pointers ----------------------------------- */
+/* v_tc: float32 [T][ld].  One launch: Normalize on each value as it enters the fill phase (normalize.c:16-24; a value
+   failing the range check of :21 gives that channel DEGA_ERROR_INVALID_VALUE), then diff -> seg -> bac as above.  No int32
+   intermediate exists in HBM.  valuesize 1..64.  decode: Denormalize (:36-38) in the row write; out_count NULL = exactly
+   T samples per channel, else up to T and the counts are reported. */
+int dega_hip_encode_f32_dev(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
+                            uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
+int dega_hip_decode_f32_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
+                            float factor, int adaptive, int valuesize, float *v_tc, uint64_t *out_count, int32_t *err, void *stream);
+
+/* ---- host pointers: the pipelined path DCCLI's stage loop (DCCLI/src/cli.c:430-466) ends up on ---------------------------- */
+/* `samples` and the outputs are HOST memory (pageable or pinned).  The batch is cut into chunks of channels, each on a
+   stream of its own: upload of its columns, kernels, packing, download of its stream bytes -- copies and kernels of
+   different chunks overlap, device and pinned buffers belong to the context and only grow, and only stream bytes come
+   back: channel c occupies packed[offsets[c] .. offsets[c+1]) (ceil(bits / 8) bytes, channel order; offsets has C + 1
+   entries).  If packed_cap is too small the call returns DEGA_ERROR_MEMORY with the size needed in offsets[C] (bits and err
+   are valid then).  decode: the inverse; out_count NULL = every channel holds exactly T samples, else up to T and the
+   counts are reported (a DCLib stream has no header: bac.c:256). */
+int dega_hip_encode_job_host(dega_hip_ctx *ctx, const dega_hip_job *job, const void *samples, uint8_t *packed, size_t packed_cap,
+                             uint64_t *offsets, uint64_t *out_bits, int32_t *err);
+int dega_hip_decode_job_host(dega_hip_ctx *ctx, const dega_hip_job *job, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits,
+                             void *samples, uint64_t *out_count, int32_t *err);
+
+/* ---- every GPU of the node: channel ranges per device, host-side concatenate, no collective ------------------------------- */
+/* Channels are independent units (every stream starts from last_value = 0, DCLib/src/diff.c:11, and InitModel(),
+   DCLib/src/bac.c:150), so a batch shards as contiguous channel ranges [g*C/G, (g+1)*C/G): one context, one host thread
+   and one set of streams per device; every device packs its own streams and copies them to their final place in `packed`
+   once the sizes of the ranges in front of it are known.  Same arguments and results as the single-context calls above --
+   a group of one IS that call.  devices NULL / n <= 0: every visible device, or the comma separated list in the
+   environment variable DEGA_DEVICES (DEGA_DEVICE for a single index). */
+/* The partition itself (no GPU needed): cuts[g] .. cuts[g+1] is device g's channel range, cuts has G + 1 entries; ranges
+   are whole 512-channel workgroup pairs where the batch is large enough. */
+int dega_hip_split_channels(size_t C, int G, size_t *cuts);
+int dega_hip_group_create(const int *devices, int n, dega_hip_group **group);
+void dega_hip_group_destroy(dega_hip_group *group);
+int dega_hip_group_size(const dega_hip_group *group);
+dega_hip_ctx *dega_hip_group_context(dega_hip_group *group, int i); /* member i (for the LZMH calls, profiling, last_error) */
+const char *dega_hip_group_last_error(const dega_hip_group *group);
+int dega_hip_group_encode(dega_hip_group *group, const dega_hip_job *job, const void *samples, uint8_t *packed, size_t packed_cap,
+                          uint64_t *offsets, uint64_t *out_bits, int32_t *err);
+int dega_hip_group_decode(dega_hip_group *group, const dega_hip_job *job, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits,
+                          void *samples, uint64_t *out_count, int32_t *err);
+
+/* Pinned host memory for callers that can keep their samples there: copies then run at link speed without the
+   runtime's staging of pageable memory.  NULL when there is no GPU runtime. */
+void *dega_hip_pinned_alloc(size_t bytes);
+void dega_hip_pinned_free(void *p);
+
+/* ---- host pointers, the earlier forms (slabs in and out; the same pipeline underneath) --------------------------------- */
 int dega_hip_encode_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                          uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
 int dega_hip_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
@@ -153,7 +221,8 @@ int dega_hip_encode_packed_host(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C
    = every channel holds exactly T samples, else up to T and the counts are reported (as dega_hip_decode_var_host). */
 int dega_hip_decode_packed_host(dega_hip_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, size_t T,
                                 size_t ld, int adaptive, int valuesize, int32_t *x_tc, uint64_t *out_count, int32_t *err);
-/* float32 channels in, DEGA streams out: normalize + encode fused on the device (and the inverse). */
+/* float32 channels in, DEGA streams out: Normalize runs inside the encode kernel, Denormalize inside the decode kernel
+   (one launch per direction, valuesize 1..64). */
 int dega_hip_encode_f32_host(dega_hip_ctx *ctx, const float *v_tc, size_t C, size_t T, size_t ld, float factor, int adaptive, int valuesize,
                              uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err);
 int dega_hip_decode_f32_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,

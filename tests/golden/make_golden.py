@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs):
   kats.json            known-answer vectors re-generated through the reference library
   channels.npz         small int32 channel batches [T][C] + the reference's per-channel DEGA streams
   floats.npz           float32 edge cases + the reference's normalize / denormalize results
+  floats_vs.npz        float32 channels through the whole chain at valuesize 8..64 (the float entry at other value sizes)
   valuesizes64.npz     the same for valuesize 33..64 (uint64 samples), including differences the decoder cannot take back
   valuesizes.npz       channel batches for valuesize 1..31 (unsigned valuesize-bit samples) + the reference's streams of
                        `encode diff valuesize=n # encode seg valuesize=n # encode bac [adaptive]`, error channels included
@@ -199,6 +200,63 @@ def floats():
     print("floats:", v.size, "edge rets", rets, "2^31:", ret, b.hex())
 
 
+def floats_vs():
+    """The float entry at other value sizes (fdega valuesize=n): per channel the reference's
+    `encode normalize normalization_factor=f valuesize=n # encode diff valuesize=n # encode seg valuesize=n # encode bac adaptive`
+    stream, and what the inverse chain gives back as float32 -- 1..64 bits, error channels included."""
+    rng = np.random.default_rng(2026)
+    out = {}
+    sets = []
+    for vs, factor in ((8, 1.0), (12, 10.0), (16, 100.0), (24, 100.0), (31, 1000.0), (32, 0.5), (33, 100.0), (40, 1000.0), (48, 100.0), (63, 1.0), (64, 100.0)):
+        T, Cn = 96, 8
+        half = float(2 ** (vs - 1))
+        v = np.zeros((T, Cn), dtype=np.float32)
+        for c in range(Cn):
+            kind = c % 4
+            # normalized values must stay non-negative and steps within +-2^(vs-1) (diff.c:15-18)
+            scale = min(half / factor, 3.0e6)
+            if kind == 0:
+                col = np.abs(np.cumsum(rng.normal(0, scale / 400, T)) + scale / 4)
+            elif kind == 1:
+                col = rng.uniform(0, scale / 2.5, T)
+            elif kind == 2:
+                col = np.abs(np.cumsum(rng.normal(0, scale / 4000, T)) + scale / 8)
+                col[T // 2] = half * 4.0 / factor  # out of range: ERROR_INVALID_VALUE (normalize.c:21-22)
+            else:
+                col = np.round(rng.uniform(0, min(scale / 3, 400.0), T), 2)
+            v[:, c] = col.astype(np.float32)
+        tag = "vs%d" % vs
+        sets.append(tag)
+        out[tag + ".v"] = v
+        out[tag + ".factor"] = np.array([factor], dtype=np.float32)
+        opt = " valuesize=%d" % vs
+        streams, bits, errs, backs = [], [], [], []
+        for c in range(Cn):
+            col = np.ascontiguousarray(v[:, c])
+            ret, b, nb, _ = orc.ref_run_chain(col.tobytes(), col.size * 32, ["encode normalize normalization_factor=%r" % factor + opt, "encode diff" + opt,
+                                                                              "encode seg" + opt, "encode bac adaptive"])
+            streams.append(b if ret == 0 else b"")
+            bits.append(nb if ret == 0 else 0)
+            errs.append(ret)
+            back = np.zeros(T, dtype=np.float32)
+            if ret == 0:
+                rd, d, dn, _ = orc.ref_run_chain(b, nb, ["decode bac adaptive", "decode seg" + opt, "decode diff" + opt,
+                                                         "decode normalize normalization_factor=%r" % factor + opt])
+                assert rd == 0 and dn == 32 * T, (vs, c, rd, dn)
+                back = np.frombuffer(d, dtype=np.float32).copy()
+            backs.append(back)
+        cap = max(1, max(len(s_) for s_ in streams))
+        arr = np.zeros((Cn, cap), dtype=np.uint8)
+        for c, s_ in enumerate(streams):
+            arr[c, : len(s_)] = np.frombuffer(s_, dtype=np.uint8)
+        out[tag + ".stream"] = arr
+        out[tag + ".bits"] = np.array(bits, dtype=np.uint64)
+        out[tag + ".err"] = np.array(errs, dtype=np.int32)
+        out[tag + ".back"] = np.stack(backs, axis=1)
+    np.savez_compressed(os.path.join(HERE, "floats_vs.npz"), **out)
+    print("floats_vs:", {t: int((out[t + ".err"] != 0).sum()) for t in sets}, "(channels in error)")
+
+
 def pack_be(vals, vs):
     """unsigned values as vs-bit big-endian fields -> (bytes, nbits): what a stage reads with valuesize=vs"""
     v = np.asarray(vals, dtype=np.uint64)
@@ -363,12 +421,16 @@ if __name__ == "__main__":
     if only == ["lzmh"]:
         lzmh()
         sys.exit(0)
+    if only == ["floats_vs"]:
+        floats_vs()
+        sys.exit(0)
     if only == ["valuesizes"]:
         valuesizes()
         valuesizes64()
         sys.exit(0)
     channels()
     floats()
+    floats_vs()
     valuesizes()
     valuesizes64()
     lzmh()

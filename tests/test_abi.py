@@ -53,3 +53,34 @@ def test_null_context_is_rejected(dca):
     L = dca.library()
     assert L.dega_hip_encode_dev(None, None, 1, 1, 1, 1, 32, None, 4, None, None, None) == dca.ERROR_INVALID_VALUE
     assert L.dega_hip_profile(None, 1) == dca.ERROR_INVALID_VALUE
+
+
+def test_channel_partition_of_a_group(dca):
+    """The per-GPU batch split of the multi-device entry points (no GPU needed): contiguous ranges in channel order that
+    cover the batch exactly, balanced, whole 512-channel units for large batches; shards of an empty or tiny batch may
+    be empty.  Channels are independent units (DCLib/src/diff.c:11, bac.c:150), so this partition is the whole story."""
+    import ctypes as C
+    L = dca.library()
+    for Cn in (0, 1, 7, 511, 512, 513, 4096, 65536, 65537, 1048576, 8388608, 1000003):
+        for G in (1, 2, 3, 4, 8):
+            cuts = (C.c_size_t * (G + 1))()
+            assert L.dega_hip_split_channels(Cn, G, cuts) == 0
+            cuts = list(cuts)
+            assert cuts[0] == 0 and cuts[-1] == Cn and all(a <= b for a, b in zip(cuts, cuts[1:])), (Cn, G, cuts)
+            sizes = [b - a for a, b in zip(cuts, cuts[1:])]
+            if Cn >= G * 1024:
+                assert all(c % 512 == 0 for c in cuts[1:-1]), (Cn, G, cuts)
+                assert max(sizes) - min(sizes) <= 1024, (Cn, G, sizes)
+            else:
+                assert max(sizes) - min(sizes) <= 1, (Cn, G, sizes)
+    assert L.dega_hip_split_channels(10, 0, None) == dca.ERROR_INVALID_VALUE
+
+
+def test_group_without_gpu_fails_loudly(dca):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(dca.DegaError) as e:
+        dca.Group()
+    assert e.value.code == dca.ERROR_LIBRARY_INIT
+    assert dca.library().dega_hip_group_size(None) == 0

@@ -38,6 +38,7 @@ def lib():
     L.GetNumberOfOptions.restype = C.c_size_t
     L.OptionNameExists.argtypes = [C.c_char_p]
     L.EncoderSupportsOption.argtypes = [C.c_char_p, C.c_char_p]
+    L.EncoderFromFunctionSupportsOption.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
     L.GetOptionType.argtypes = [C.c_char_p]
     for n, t in (("Bool", C.c_int), ("Size", C.c_size_t), ("Float", C.c_float), ("Char", C.c_char)):
         getattr(L, "SetOptionValue" + n).argtypes = [C.POINTER(Options), C.c_char_p, t]
@@ -90,6 +91,22 @@ def test_option_table_and_defaults(lib):
     assert lib.GetOptionValueSize(C.byref(o), b"valuesize", C.byref(v)) == 0 and v.value == 16
     assert lib.EncoderSupportsOption(b"dega", b"adaptive") and lib.EncoderSupportsOption(b"fdega", b"normalization_factor")
     assert not lib.EncoderSupportsOption(b"dega", b"normalization_factor") and not lib.EncoderSupportsOption(b"copy", b"adaptive")
+
+
+def test_option_support_by_function_pointer(lib):
+    """EncoderFromFunctionSupportsOption (DCLib/inc/enc_dec.h:59, DCLib/src/enc_dec.c:216-225; used by DCCLI/src/cli.c:305):
+    the option mask of the row a codec FUNCTION belongs to, looked up by encoder or by decoder pointer."""
+    class EncDec(C.Structure):
+        _fields_ = [("encoder", C.c_void_p), ("decoder", C.c_void_p)]
+    dega = EncDec.from_address(lib.GetEncoder(b"dega"))
+    fdega = EncDec.from_address(lib.GetEncoder(b"fdega"))
+    copy = EncDec.from_address(lib.GetEncoder(b"copy"))
+    f = lib.EncoderFromFunctionSupportsOption
+    assert f(dega.encoder, 1, b"adaptive") and f(dega.decoder, 0, b"valuesize") and f(dega.encoder, 1, b"num_channels")
+    assert not f(dega.encoder, 1, b"normalization_factor") and f(fdega.decoder, 0, b"normalization_factor")
+    assert not f(dega.encoder, 0, b"adaptive")  # an encoder pointer is not a decoder (enc_dec.c:221)
+    assert f(copy.encoder, 1, b"blocksize") and not f(copy.encoder, 1, b"adaptive")
+    assert not f(dega.encoder, 1, b"nonsense") and not f(None, 1, b"adaptive")
 
 
 def test_bit_stream_format(lib):
@@ -262,5 +279,113 @@ def test_cli_dega_with_valuesize(lib, tmp_path):
         p = run_cli([str(enc), str(back), "decode", "dega", "adaptive", "valuesize=%d" % vs])
         assert p.returncode == 0, p.stderr
         assert back.read_bytes() == packed, vs
-    p = run_cli([str(src), str(enc), "encode", "fdega", "valuesize=40"])  # the float entry ends at 32 (normalize on int32)
+    p = run_cli([str(src), str(enc), "encode", "fdega", "valuesize=65"])  # 1..64, as the reference's option table (enc_dec.c:72)
     assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_cli_fdega_valuesizes_against_the_reference(lib, tmp_path):
+    """`fdega valuesize=n` (Normalize inside the encode kernel, Denormalize inside the decode kernel) for n = 8..64: the
+    stream and the floats coming back are the compiled reference's (tests/golden/floats_vs.npz, made by make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "floats_vs.npz"))
+    for tag in sorted({k.split(".")[0] for k in z.files}, key=lambda t: int(t[2:])):
+        vs, factor = int(tag[2:]), float(z[tag + ".factor"][0])
+        v = z[tag + ".v"]
+        for c in (0, 1, 3, 2):  # 2 is the channel that fails the range check of normalize.c:21
+            src = tmp_path / "v.f32"
+            src.write_bytes(np.ascontiguousarray(v[:, c]).tobytes())
+            enc = tmp_path / "v.dega"
+            p = run_cli([str(src), str(enc), "encode", "fdega", "adaptive", "valuesize=%d" % vs, "normalization_factor=%r" % factor])
+            if int(z[tag + ".err"][c]) != 0:
+                assert p.returncode == 245 and "Invalid value" in p.stderr, (tag, c)
+                continue
+            assert p.returncode == 0, (tag, c, p.stderr)
+            nb = int(z[tag + ".bits"][c])
+            assert enc.read_bytes() == z[tag + ".stream"][c, : (nb + 7) // 8].tobytes(), (tag, c)
+            back = tmp_path / "back.f32"
+            p = run_cli([str(enc), str(back), "decode", "fdega", "adaptive", "valuesize=%d" % vs, "normalization_factor=%r" % factor])
+            assert p.returncode == 0, (tag, c, p.stderr)
+            assert back.read_bytes() == np.ascontiguousarray(z[tag + ".back"][:, c]).tobytes(), (tag, c)
+
+
+@pytest.mark.gpu
+def test_cli_long_single_stream_round_trip(lib, tmp_path):
+    """A bare (headerless) stream larger than 2 MiB: the decoder's first guess at the sample count is clamped to what one
+    library call takes (2^25) instead of being rejected, so encode -> decode round-trips (the reference has no such limit)."""
+    rng = np.random.default_rng(77)
+    T = 1 << 20
+    x = rng.integers(0, 1 << 30, T).astype(">i4")  # ~60 coded bits per sample: a stream of ~7.5 MiB
+    src = tmp_path / "noise.be32"
+    src.write_bytes(x.tobytes())
+    enc = tmp_path / "noise.dega"
+    p = run_cli([str(src), str(enc), "encode", "dega", "adaptive"])
+    assert p.returncode == 0, p.stderr
+    assert enc.stat().st_size > (2 << 20)
+    back = tmp_path / "noise.back"
+    p = run_cli([str(enc), str(back), "decode", "dega", "adaptive"])
+    assert p.returncode == 0, p.stderr
+    assert back.read_bytes() == x.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_damaged_container_headers_are_rejected(lib, tmp_path):
+    """Nothing of a DEGB header is trusted: channel / sample counts and bit lengths that do not fit the bytes that follow
+    (including lengths near 2^64, whose rounding to bytes would wrap) give ERROR_INVALID_FORMAT, not a kernel launch."""
+    rng = np.random.default_rng(3)
+    T, Cn = 64, 5
+    x = (np.cumsum(rng.integers(-9, 10, (T, Cn)), axis=0) + 500).astype(">i4")
+    src = tmp_path / "b.be32"
+    src.write_bytes(x.tobytes())
+    enc = tmp_path / "b.degb"
+    assert run_cli([str(src), str(enc), "encode", "dega", "adaptive", "num_channels=%d" % Cn]).returncode == 0
+    good = bytearray(enc.read_bytes())
+    out = tmp_path / "b.out"
+
+    def decode(blob):
+        bad = tmp_path / "bad.degb"
+        bad.write_bytes(bytes(blob))
+        return run_cli([str(bad), str(out), "decode", "dega", "adaptive", "num_channels=%d" % Cn])
+
+    assert decode(good).returncode == 0 and out.read_bytes() == x.tobytes()
+    for at, value in ((24, (1 << 64) - 3), (24 + 8, (1 << 63)), (24 + 16, 8 * len(good)), (16, 1 << 40), (16, (1 << 64) - 1), (8, Cn + 1), (8, 1 << 61)):
+        blob = bytearray(good)
+        blob[at: at + 8] = value.to_bytes(8, "big")
+        p = decode(blob)
+        assert p.returncode == 245 and "Invalid format" in p.stderr, (at, value, p.stderr)
+    assert decode(good[:30]).returncode == 245
+    # a stream cut short inside a channel is that channel's decode error, not a crash
+    p = decode(good[: len(good) - 7])
+    assert p.returncode == 245
+
+
+@pytest.mark.gpu
+def test_cli_glzmh_batch_container(lib, tmp_path):
+    """`glzmh num_channels=n`: the input cut into n pieces, each a stream of its own in one launch ("LZMB" container); every
+    inner stream is what the reference's `encode lzmh` makes of that piece, and decode restores the text."""
+    from oracle import orc
+    with gzip.open(os.path.join(GOLDEN, "input.txt.gz"), "rb") as f:
+        raw = f.read()[:120000]
+    src = tmp_path / "text.txt"
+    src.write_bytes(raw)
+    enc, back = tmp_path / "text.lzmb", tmp_path / "text.back"
+    n = 7
+    p = run_cli([str(src), str(enc), "encode", "glzmh", "num_channels=%d" % n])
+    assert p.returncode == 0, p.stderr
+    blob = enc.read_bytes()
+    assert blob[:4] == b"LZMB" and int.from_bytes(blob[8:16], "big") == n
+    piece = (len(raw) + n - 1) // n
+    off = 16 + 16 * n
+    for c in range(n):
+        want_len, nbits = int.from_bytes(blob[16 + 16 * c: 24 + 16 * c], "big"), int.from_bytes(blob[24 + 16 * c: 32 + 16 * c], "big")
+        part = raw[c * piece: (c + 1) * piece]
+        assert want_len == len(part)
+        r, b, nb = orc.stage("lzmh", True, part, 8 * len(part))
+        assert r == 0 and nb == nbits and blob[off: off + (nb + 7) // 8] == b[: (nb + 7) // 8], c
+        off += (nbits + 7) // 8
+    p = run_cli([str(enc), str(back), "decode", "glzmh", "num_channels=%d" % n])
+    assert p.returncode == 0, p.stderr
+    assert back.read_bytes() == raw
+    bad = bytearray(blob)
+    bad[24:32] = ((1 << 64) - 1).to_bytes(8, "big")
+    (tmp_path / "bad.lzmb").write_bytes(bytes(bad))
+    assert run_cli([str(tmp_path / "bad.lzmb"), str(back), "decode", "glzmh", "num_channels=%d" % n]).returncode == 245

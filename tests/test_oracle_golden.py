@@ -201,3 +201,31 @@ def test_restatement_equals_compiled_reference_on_random_streams():
             assert a[0] == r[0], (it, spec, a[0], r[0])
             if a[0] == 0:
                 assert (a[1], a[2]) == (r[1], r[2]), (it, spec)
+
+
+def test_float_entry_at_other_value_sizes():
+    """The restatement's normalize -> diff -> seg -> bac chain at valuesize 8..64 (io_int_t = int64 arithmetic of
+    normalize.c:21-24 included) against the compiled reference's streams, error verdicts and decoded floats
+    (tests/golden/floats_vs.npz)."""
+    z = np.load(os.path.join(GOLDEN, "floats_vs.npz"))
+    tags = sorted({k.split(".")[0] for k in z.files}, key=lambda t: int(t[2:]))
+    assert len(tags) >= 10
+    for tag in tags:
+        vs, f = int(tag[2:]), float(z[tag + ".factor"][0])
+        v = z[tag + ".v"]
+        for c in range(v.shape[1]):
+            col = np.ascontiguousarray(v[:, c])
+            data, n, ret = col.tobytes(), col.size * 32, 0
+            for name in ("normalize", "diff", "seg", "bac"):
+                ret, data, n = orc.stage(name, True, data, n, valuesize=vs, adaptive=1, factor=f)
+                if ret != 0:
+                    break
+            assert ret == int(z[tag + ".err"][c]), (tag, c)
+            if ret != 0:
+                continue
+            nb = int(z[tag + ".bits"][c])
+            assert n == nb and data[: (n + 7) // 8] == z[tag + ".stream"][c, : (nb + 7) // 8].tobytes(), (tag, c)
+            for name in ("bac", "seg", "diff", "normalize"):
+                r, data, n = orc.stage(name, False, data, n, valuesize=vs, adaptive=1, factor=f)
+                assert r == 0, (tag, c, name)
+            assert data == np.ascontiguousarray(z[tag + ".back"][:, c]).tobytes(), (tag, c)
