@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   uint32_t iter = 0;
   uint32_t Mnext[32]; // division magics of the next fast word, see BacEncoder::fetch_magics
   enc.fetch_magics(tab, Mnext);
+  uint32_t word = 0;  // the queued word a lane codes next, read from its ring column a step early
   DG_STAMP_DECL;
   for (;;)
   {
@@ -317,47 +318,54 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     DG_STAMP(2);
     if (any_has)
     {
-      // wave uniform choice: the fast word (no model event possible in it), the general word (halving / swap / shift
-      // change handled branch free), or bit by bit (first word of a channel, leftovers in the LDS column)
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 1024)
-      const bool fast = iter > 8; // diagnostic build: no precondition ballots
-      const bool general = false;
-#else
-      const bool fast = wave_all(!has || enc.fast_ok());
-      const bool general = ADAPTIVE && !fast && wave_all(!has || enc.general_ok());
-#endif
+      // Which word path?  Every lane knows the class of its next word and for how many words that class still holds
+      // (BacEncoder::classify: looked at again only when the count has run out); the wave takes the most expensive
+      // class among its lanes.  In the steady state this is one ballot.
+      if (wave_any(has && enc.safe == 0u))
+      {
+        if (has && enc.safe == 0u)
+          enc.classify();
+      }
+      const uint32_t cls = has ? enc.cls : CLS_FAST8;
+      uint32_t record = 0, groups = 4; // a carry past the held-back word, recorded by the word path (see settle_ripples)
+      if (!wave_any(cls != CLS_FAST8))
+      {
+        if (has)
+          record = enc.template encode_word<false, 8>(word, tab, Mnext);
+        DG_STAMP(3);
+      }
+      else
+      {
+        const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
+        groups = 8;
+        if (has)
+        {
+          if (any_bits)
+          {
+#pragma unroll 1
+            for (uint32_t i = 0; i < 32; i++)
+              enc.encode_bit((word >> (31u - i)) & 1u, tab);
+          }
+          else if (any_general)
+          {
+            if constexpr (ADAPTIVE)
+              record = enc.template encode_word<true, 4>(word, tab, Mnext);
+          }
+          else
+            record = enc.template encode_word<false, 4>(word, tab, Mnext);
+        }
+        DG_STAMP(4);
+      }
+      if (wave_any(record != 0u)) // once in 2^32 hand-overs of random data
+      {
+        if (record != 0u)
+          enc.settle_word(record, groups);
+      }
       if (has)
       {
-        const uint32_t word = ring_col[(q.rd % RING) * 64u];
         q.rd++;
-        bool done = false;
-        if (fast || general)
-        {
-          const BacEncoder<ADAPTIVE, ORING> checkpoint = enc;
-          if (fast)
-            done = enc.encode_word_fast(word, Mnext);
-          else if constexpr (ADAPTIVE)
-            done = enc.encode_word_general(word, tab);
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 512)
-          done = true; // diagnostic build: no checkpoint / redo
-#endif
-          if (!done)
-            enc = checkpoint; // a carry ran past the held-back word, or > 48 bits piled up: redo exactly
-        }
-        if (!done)
-        {
-#pragma unroll 1
-          for (uint32_t i = 0; i < 32; i++)
-            enc.encode_bit((word >> (31u - i)) & 1u, tab);
-        }
+        enc.safe -= enc.safe != 0u ? 1u : 0u;
       }
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-      if (fast)
-        DG_STAMP(3);
-      else
-        DG_STAMP(4);
-      (void)general;
-#endif
     }
     enc.fetch_magics(tab, Mnext); // for the next code step; in flight during fill and drain
     // ---- phase F: the same ROWS rows for every lane ----------------------------------------------------------
@@ -434,26 +442,25 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
               xr[i] &= vmask;
           }
         }
-        // Pass 1, no side effects: the codeword values of the whole batch, assuming short codewords (|delta| < 2^15).
+        // Pass 1, no side effects: the codeword values of the whole batch, assuming the steady state -- every sample
+        // below 2^31 (then every difference fits, diff.c:17-18) and every codeword short (|delta| < 2^15): one OR over
+        // the batch answers both
         uint32_t w[ROWS];
-        uint32_t last_try = last;
-        bool all_ok = true, any_wide = false;
+        uint32_t last_try = last, seen = last, wseen = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ROWS; i++)
         {
-          bool ok, wide;
-          w[i] = diff_seg_short<NARROW>(xr[i], last_try, ok, wide, vhalf);
-          all_ok = all_ok && ok;
-          any_wide = any_wide || wide;
+          w[i] = diff_seg_steady(xr[i], last_try);
+          seen |= xr[i];
+          wseen |= w[i];
         }
-        if (left >= ROWS && !wave_any(any_wide && live))
+        const bool plain = NARROW ? false : ((seen >> 31) | (wseen >> 16)) == 0u; // narrow values: range check per sample
+        if (left >= ROWS && !wave_any(!plain && live))
         {
           // the steady state: a full batch of short codewords, straight-line appends
           if (live)
           {
             last = last_try;
-            if (!all_ok && lane_err == OK)
-              lane_err = ERR_INVALID_VALUE;
 #pragma unroll
             for (uint32_t i = 0; i < ROWS; i++)
               q.put_short<RING>(w[i], ring_col);
@@ -461,7 +468,8 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
         }
         else if (live)
         {
-          // first samples of a channel, jumps, the last partial batch: the general three-piece writer, row by row
+          // first samples of a channel, jumps, narrow value sizes, the last partial batch: the general three-piece
+          // writer, row by row
 #pragma unroll
           for (uint32_t i = 0; i < ROWS; i++)
           {
@@ -482,6 +490,8 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     }
     else if (!any_has)
       break; // all rows consumed and every queue drained
+    // the word of the next code step: read now, needed a drain and a loop top later
+    word = ring_col[(q.rd % RING) * 64u];
     // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
     // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
     iter++;
@@ -521,9 +531,9 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   {
     // the last, partial word of the seg stream, then EOF + flush (bac.c:163-164)
     const uint32_t tail = q.cnt;
-    const uint32_t word = tail ? (uint32_t)(q.acc << (32u - tail)) : 0u;
+    const uint32_t tword = tail ? (uint32_t)(q.acc << (32u - tail)) : 0u;
     for (uint32_t i = 0; i < tail; i++)
-      enc.encode_bit((word >> (31u - i)) & 1u, tab);
+      enc.encode_bit((tword >> (31u - i)) & 1u, tab);
     a.out_bits[c] = enc.finish(tab);
     a.err[c] = lane_err != OK ? lane_err : enc.err;
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)

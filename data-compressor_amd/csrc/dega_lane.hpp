@@ -12,9 +12,9 @@
 // Cost model this code is written against (profiles/r01_ubench_issue_cost.txt, measured on MI355X): a wave issues one
 // instruction every ~4 cycles whatever it is (VALU add, 32x32 multiply, 64-bit shift, SALU, LDS), and more waves per
 // SIMD do not raise the VALU rate -- so time = instruction count, and a divergent `if` costs its exec-mask SALU
-// bookkeeping on every pass.  Hence: an unrolled, branch-free 32-symbol fast path with selects, every rare event
-// (model halving, MPS/LPS swap, a carry running past the word kept back for it, slab nearly full) moved to a
-// per-word precondition or a checkpoint-and-redo, and a general bit-at-a-time slow path that handles everything.
+// bookkeeping on every pass.  Hence: unrolled, branch-free 32-symbol word paths with selects, every rare event
+// (model halving, MPS/LPS swap, too many finished bits between two hand-overs, slab nearly full) moved to a
+// precondition that is looked at once per many words, and a bit-at-a-time slow path that handles everything.
 #pragma once
 
 #include <stdint.h>
@@ -139,6 +139,20 @@ DG_DEV uint32_t not_hi16(uint32_t x)
 #endif
 }
 
+// range = 65536 - (x >> 16) for x = A + B in one instruction (SDWA: the high word of x as the subtrahend); x = 0 is the
+// full range 65536, which is why this is not simply -x >> 16
+DG_DEV uint32_t range_from_sum(uint32_t x)
+{
+#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 64))
+  return 0x10000u - (x >> 16);
+#else
+  uint32_t r;
+  const uint32_t full = 0x10000u;
+  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(full), "v"(x));
+  return r;
+#endif
+}
+
 // Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic[t]) >> shift(t)  with
 // magic = ceil(2^(30+L) / t), L = ceil(log2 t), shift = L - 2: the error term n*(magic*t - 2^(30+L)) / (t * 2^(30+L)) is
 // below 2^-L <= 1/t, so the floor cannot move.  This replaces the two 64-bit divisions per symbol of bac.c:110-111
@@ -158,48 +172,68 @@ DG_DEV uint32_t div_shift(uint32_t t)
 // E3 step the reference clears the top bit of both; here it is left set in both ("spurious" bit 31): every use either
 // shifts it out or cancels it (A + B mod 2^32, A ^ B).
 //
-// Output side: a carry-propagating accumulator instead of bit-plus-follow.  The reference emits a bit per E1/E2 shift
-// and defers E3 shifts in a counter resolved by the next emitted bit (bac.c:93-105,127-132).  The stream it produces is
-// exactly the binary expansion of the running sum of the `start` increments, each added at the current window
-// position: an E3 shift provisionally emits 0 then 1s and a later carry out of the window flips them, which is what a
-// multi-word addition does.  So the lane keeps
-//   W    = [ finished bits | 16-bit window | zeros ], left aligned in 64 bits; wsh = bit index of the window's LSB
-//   prev = the last completed 32-bit word, held back from memory so that it can still absorb carries out of W
-//   pc   = carries that left W since prev was taken
-// and stores prev + pc when the next word completes.  A carry running even past prev (33+ pending bits) is rippled
-// into the words already stored, which this lane wrote itself.
+// Output side: carry propagation instead of bit-plus-follow.  The reference emits a bit per E1/E2 shift and defers E3
+// shifts in a counter resolved by the next emitted bit (bac.c:93-105,127-132).  The stream it produces is exactly the
+// binary expansion of the running sum of the `start` increments, each added at the current position: an E3 shift
+// provisionally emits 0 then 1s and a later carry flips them, which is what a multi-word addition does.  So the lane
+// keeps ONE 64-bit register
+//   L = [ 1 | c | finished bits ] : [ A ]        high dword : low dword
+// A is the interval's start as above; every `start` increment is a 64-bit add into L (the carry out of A lands in the
+// finished bits by itself) and every renormalisation a 64-bit shift (the bits leaving A become finished bits by
+// themselves).  The high dword starts as binary 10: the leading one is a sentinel whose position tells how many bits are
+// finished (no counter to keep per symbol), the zero below it takes a carry that runs past ALL finished bits (it can
+// take one: a pending run starts with a provisional 0, so a second such carry needs a new run, which stays inside).
+// Every few symbols the finished bits -- at most 30 fit -- are DUMPED into
+//   F    = finished bits not yet in whole words, right aligned, fcnt of them (< 32 between dumps, + the dump's <= 30,
+//          + 1 for the carry: never more than 62, so F cannot overflow)
+//   prev = the last completed 32-bit word, held back from memory so that it can still absorb a carry out of F
+// and whole words are handed on: prev (+ that carry) to the lane's LDS column, the new word to prev.  A carry running even
+// past prev (33+ pending bits) ripples into the words already stored, which this lane wrote itself.
+//
+// How many symbols may go between two dumps?  n symbols shift out fewer than 2 + sum(-log2 p_i) bits (the range starts
+// and ends the group in (Q, 4Q]), and no symbol is less probable than f2 / tot, so with tot <= 11 * f2 eight symbols
+// stay below 2 + 8 * 3.46 < 30 bits, and with tot <= 128 * f2 four do.  These are per-word preconditions (classify());
+// a lane outside both codes bit by bit and dumps after every symbol.
 //
 // Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
 // frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t ENC_WORD_MAX_OUT = 16; // the most one 32-symbol word can complete (32 * 16 bits)
-constexpr uint32_t ENC_ORING = 32;        // staged output words per lane; word paths need ENC_WORD_MAX_OUT free slots
+constexpr uint32_t ENC_WORD_MAX_OUT = 8; // the most one 32-symbol word path can complete: 8 groups of < 30 bits
+constexpr uint32_t ENC_ORING = 32;       // staged output words per lane; word paths need ENC_WORD_MAX_OUT free slots
+
+// classes of the next 32 symbols of a lane, cheapest first (the wave takes the most expensive one any of its lanes needs)
+constexpr uint32_t CLS_FAST8 = 0;   // no model event possible, a dump every 8 symbols is enough
+constexpr uint32_t CLS_FAST4 = 1;   // no model event possible, skewed counts: a dump every 4 symbols
+constexpr uint32_t CLS_GENERAL = 2; // halving / MPS-LPS swap / division-shift change handled by selects, dump every 4
+constexpr uint32_t CLS_BITS = 3;    // bit at a time: first word of a channel, extreme counts
 
 template <bool ADAPTIVE, uint32_t ORING = ENC_ORING>
 struct BacEncoder
 {
-  uint32_t A, B;
+  uint64_t L; // low dword: A; high dword: sentinel, carry slot, finished bits (see above)
+  uint32_t B;
   uint32_t c1, tot, mps;
-  uint64_t W;
-  uint32_t wsh;
-  uint32_t prev, pc, pos;   // pos = words completed so far; prev is word pos-1 (held back)
+  uint64_t F;
+  uint32_t fcnt;
+  uint32_t prev, pos;       // pos = words completed so far; prev is word pos-1 (held back)
   uint32_t drained, staged; // words [0, drained) are in the slab, [drained, drained + staged) in the lane's LDS column
   uint32_t cap_words;
   uint32_t *dst;   // channel's slab (global memory)
   uint32_t *oring; // lane's column of the LDS output ring: slot s at oring[s * 64]
   int32_t err;
+  uint32_t safe;   // words that may still be coded in class `cls` before the preconditions have to be looked at again
+  uint32_t cls;
 
   DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
   {
-    A = 0; // bac.c:86-91
+    L = (uint64_t)2 << 32; // bac.c:86-91: start = 0; no finished bits
     B = 0;
     c1 = 2; // bac.c:39-52
     tot = 3;
     mps = 0;
-    W = 0;
-    wsh = 48;
+    F = 0;
+    fcnt = 0;
     prev = 0;
-    pc = 0;
     pos = 0;
     drained = 0;
     staged = 0;
@@ -207,9 +241,16 @@ struct BacEncoder
     dst = dst_;
     oring = oring_;
     err = OK;
+    safe = 0;
+    cls = CLS_BITS;
   }
 
-  // ---- general path: one bit at a time, every special case handled in place --------------------------------------
+  DG_DEV uint32_t A() const
+  {
+    return (uint32_t)L;
+  }
+
+  // ---- memory side ---------------------------------------------------------------------------------------------------
 
   DG_DEV void put_word(uint32_t index, uint32_t word)
   {
@@ -260,7 +301,8 @@ struct BacEncoder
     staged++;
   }
 
-  DG_DEV void ripple_carry_from(uint32_t count) // add one to the big number formed by words [0, count)
+  // add one to the big number formed by words [0, count): the staged ones first, then the slab (rare: a carry past `prev`)
+  DG_DEV void ripple_carry_from(uint32_t count)
   {
     drain_lane();
     while (count > 0)
@@ -276,47 +318,90 @@ struct BacEncoder
     }
   }
 
-  DG_DEV void store_prev()
+  // ---- finished bits -> words ------------------------------------------------------------------------------------------
+
+  // L's finished bits (and the carry above them) move to F.  Exact for any state with at most 30 finished bits.
+  DG_DEV void dump()
   {
-    if (pos > 0)
+    const uint32_t hi = (uint32_t)(L >> 32);
+    const uint32_t fb = 30u - clz32(hi);          // the sentinel sits at bit fb + 1
+    const uint32_t v = hi - (2u << fb);           // finished bits, the carry (if any) at bit fb
+    L = ((uint64_t)2 << 32) | (uint32_t)L;
+    F = (F << fb) + v;                            // the carry adds into the bits F already holds
+    fcnt += fb;
+  }
+
+  // One whole word out of F if it holds one (fcnt >= 32): prev, plus the carry that came up through F, goes to the LDS
+  // column; the new word is held back.  The general form, for the bit path and the end of the stream.
+  DG_DEV void hand_off()
+  {
+    if (fcnt < 32u)
+      return;
+    const uint32_t sh = fcnt - 32u;
+    const uint64_t top = F >> sh; // the word, above it the carry (0 or 1)
+    const uint32_t carry = (uint32_t)(top >> 32);
+    if (pos > 0u)
     {
-      const uint32_t sum = prev + pc;
-      if (sum < pc)
-        ripple_carry_from(pos - 1);
+      const uint32_t sum = prev + carry;
+      if (sum < carry) // prev was all ones: the carry runs on into words already handed on
+        ripple_carry_from(pos - 1u);
       push_word(sum);
     }
+    pos++;
+    prev = (uint32_t)top;
+    F = (uint32_t)F & ((1u << sh) - 1u);
+    fcnt = sh;
   }
 
-  DG_DEV void add_at_window(uint32_t inc)
+  // The same inside a word path: branch free, pos >= 1, room in the LDS column guaranteed by the caller.  A carry running
+  // past prev (prev all ones: once in 2^32 hand-overs of random data) is only RECORDED -- bit g of `ovf` for the g-th
+  // hand-over of the word, with `took` telling which hand-overs completed a word -- and settled after the word
+  // (settle_ripples): the words it has to run into are all in the column or the slab by then, and adding one to a
+  // multi-word number can be done at any time.
+  DG_DEV void hand_off_in_word(uint32_t &took, uint32_t &ovf)
   {
-    const uint64_t add = (uint64_t)inc << wsh;
-    const uint64_t nw = W + add;
-    pc += nw < add ? 1u : 0u;
-    W = nw;
+    const uint32_t m = (uint32_t)((int32_t)(31u - fcnt) >> 31); // all ones when a word is complete
+    const uint32_t sh = (fcnt - 32u) & 31u;
+    const uint64_t top = F >> sh;                               // the word, above it the carry; garbage when m == 0
+    const uint32_t carry = (uint32_t)(top >> 32) & m;
+    const uint32_t sum = prev + carry;
+    ovf = (ovf << 1) | (sum < carry ? 1u : 0u);
+    took = (took << 1) | (m & 1u);
+    oring[staged * 64u] = sum; // harmless when no word is complete: the slot is rewritten by the next one
+    staged += m & 1u;
+    pos += m & 1u;
+    prev = select32(m, (uint32_t)top, prev);
+    const uint32_t keep = (uint32_t)F & ((1u << sh) - 1u);
+    F = m ? (uint64_t)keep : F;
+    fcnt = select32(m, sh, fcnt);
   }
 
-  DG_DEV void advance(uint32_t n) // the window moved n bits to the right: n more finished bits
+  DG_DEV void settle_word(uint32_t record, uint32_t groups) // record: what encode_word returned (non-zero)
   {
-    wsh -= n;
-    if (wsh <= 16)
+    settle_ripples(record & 0xFFu, (record >> 16) & 0xFFu, groups);
+  }
+
+  // After a word path with `groups` hand-overs: the recorded carries past prev, each into the words in front of the word
+  // that was held back at the time.
+  DG_DEV void settle_ripples(uint32_t took, uint32_t ovf, uint32_t groups)
+  {
+    uint32_t p = pos; // words completed now; walk the hand-overs backwards
+    for (uint32_t g = 0; g < groups; g++)
     {
-      store_prev();
-      prev = (uint32_t)(W >> 32);
-      pc = 0;
-      pos++;
-      W <<= 32;
-      wsh += 32;
+      const uint32_t t = (took >> g) & 1u;
+      p -= t; // completed words before this hand-over
+      if ((ovf >> g) & 1u)
+        ripple_carry_from(p - 1u); // the held-back word was word p - 1; the carry goes into the words in front of it
     }
   }
 
-  DG_DEV uint32_t renormalise() // bac.c:112-137; returns the number of window shifts (E1/E2 + E3)
+  // ---- one symbol, every special case handled in place -----------------------------------------------------------------
+
+  DG_DEV uint32_t renormalise_count(uint32_t a, uint32_t b) const // bac.c:112-137: the number of shifts (E1/E2 + E3)
   {
-    const uint32_t k = clz32(~(A ^ B)); // <= 16: the low halves differ by construction
-    const uint32_t v = ((A & B) << k) | 0x80000000u;
-    const uint32_t n = k + clz32(~v) - 1u; // run of ones below bit 31; ~v != 0 because the low 16 bits of v are zero
-    A <<= n;
-    B <<= n;
-    return n;
+    const uint32_t k = clz32(~(a ^ b)); // <= 16: the low halves differ by construction
+    const uint32_t v = ((a & b) << k) | 0x80000000u;
+    return k + clz32(~v) - 1u; // run of ones below bit 31; ~v != 0 because the low 16 bits of v are zero
   }
 
   DG_DEV void update_model(bool lps) // bac.c:54-81
@@ -342,59 +427,111 @@ struct BacEncoder
   {
     const uint32_t M = magic[tot];
     const uint32_t sh = div_shift(tot);
-    const uint32_t R = ((~(A + B)) >> 16) + 1u;
+    const uint32_t a = A();
+    const uint32_t R = ((~(a + B)) >> 16) + 1u;
     const uint32_t x1 = mulhi32(R * c1, M) >> sh; // range * cum[1] / cum[0]
     const bool lps = bit != mps;
     uint32_t inc = x1; // index 1: end unchanged, start += x1
     if (lps)
     {
-      B = 0u - (A + (x1 << 16)); // index 2: end = start + x1 - 1 ...
+      B = 0u - (a + (x1 << 16)); // index 2: end = start + x1 - 1 ...
       inc = mulhi32(R, M) >> sh; // ... start += range * cum[2] / cum[0], cum[2] = 1   (bac.c:110-111)
     }
-    A += inc << 16;
-    add_at_window(inc);
-    advance(renormalise());
+    L += (uint64_t)(inc << 16);
+    const uint32_t n = renormalise_count(A(), B); // <= 16
+    L <<= n;
+    B <<= n;
+    dump();
+    hand_off();
     if (ADAPTIVE)
       update_model(lps);
+    safe = 0; // the model moved outside a word path: classify again
   }
 
   // EOF symbol + FinishEncoding (bac.c:163-164, 141-145); returns the exact stream length in bits
   DG_DEV uint64_t finish(const uint32_t *magic)
   {
-    const uint32_t R = ((~(A + B)) >> 16) + 1u;
+    const uint32_t a = A();
+    const uint32_t R = ((~(a + B)) >> 16) + 1u;
     const uint32_t x2 = mulhi32(R, magic[tot]) >> div_shift(tot); // index 3: cum[2] = 1, cum[3] = 0
-    B = 0u - (A + (x2 << 16));                                     // end = start + x2 - 1, start unchanged
-    advance(renormalise());
+    B = 0u - (a + (x2 << 16));                                     // end = start + x2 - 1, start unchanged
+    const uint32_t n = renormalise_count(a, B);
+    L <<= n;
+    B <<= n;
+    dump();
+    hand_off();
     // "pending++ ; emit (start < Q ? 0 : 1) and the pending inverse bits" == round the window up to the next multiple
     // of Q and emit its top two bits (the carry resolves any pending run).
-    add_at_window(0x4000u);
-    advance(2);
-    store_prev();
-    drain_lane();
-    const uint32_t cnt = 48u - wsh;
-    if (cnt > 0)
-      put_word(pos, (uint32_t)(W >> 32) & ~(0xFFFFFFFFu >> cnt)); // zero padding (bit_file_buffer.c:310-320)
-    return (uint64_t)pos * 32u + cnt;
-  }
-
-  // ---- fast path: 32 symbols, branch free except for the word hand-off ---------------------------------------------
-
-  // Preconditions for encode_word_fast on this lane (evaluated once per word):
-  DG_DEV bool fast_ok() const
-  {
-    bool ok = pos >= 1 && staged + ENC_WORD_MAX_OUT <= ORING; // a held-back word exists; room in the LDS column
-    if (ADAPTIVE)
+    L += (uint64_t)0x40000000u;
+    L <<= 2;
+    dump();
+    hand_off();
+    // what is left: prev, then the fcnt < 32 bits of F, zero padded (bit_file_buffer.c:310-320)
+    const uint32_t carry = (uint32_t)(F >> fcnt) & 1u;
+    if (pos > 0)
     {
-      ok = ok && tot + 32u <= MAX_FREQUENCY;                  // no halving during these 32 updates
-      ok = ok && tot + 1u >= 2u * c1 + 32u;                   // f1 - f2 >= 32: no MPS/LPS swap can occur
-      ok = ok && clz32(tot - 1u) == clz32(tot + 30u);         // one division shift for the whole word
+      const uint32_t sum = prev + carry;
+      if (sum < carry)
+        ripple_carry_from(pos - 1u);
+      push_word(sum);
     }
-    return ok;
+    drain_lane();
+    if (fcnt > 0)
+      put_word(pos, (uint32_t)F << (32u - fcnt));
+    return (uint64_t)pos * 32u + fcnt;
   }
 
-  // Codes the 32 bits of `word`; completed words go to the lane's LDS column (the kernel drains it afterwards).
-  // Returns false if a carry ran past `prev` (the caller restores its checkpoint and redoes the word with encode_bit).
-  // The 32 division magics of the word that a lane would code next with encode_word_fast (cum[0] = tot .. tot+31).
+  // ---- the class of the next word, and for how many words it holds -------------------------------------------------------
+  // Evaluated when `safe` has run out.  All conditions look ahead over whole words, so that in between one decrement
+  // per word is all the bookkeeping there is:
+  //   no halving          tot + 32 <= MAX_FREQUENCY at the start of each word (bac.c:57)
+  //   no MPS/LPS swap     f1 - f2 >= 32 at the start of each word (bac.c:68: needs f2 == f1; a word adds at most 32 to f2)
+  //   one division shift  tot - 1 and tot + 30 have the same bit length
+  //   dump capacity       tot <= 11 * f2 (eight symbols) or tot <= 128 * f2 (four), up to the end of each word
+  DG_DEV void classify()
+  {
+    if (pos == 0u) // nothing is held back yet: the hand-off of the first word is special
+    {
+      cls = CLS_BITS;
+      safe = 0;
+      return;
+    }
+    if (!ADAPTIVE)
+    {
+      cls = CLS_FAST8; // counts 1 : 1 : 1 forever: 8 symbols shift out fewer than 2 + 8 * log2(3) < 15 bits
+      safe = 0x40000000u;
+      return;
+    }
+    const uint32_t f2 = c1 - 1u, diff = tot + 1u - 2u * c1; // f1 - f2
+    const uint32_t w_halve = (MAX_FREQUENCY - tot) >> 5;
+    const uint32_t w_swap = diff >> 5;
+    const uint32_t pw = 0x80000000u >> (clz32(tot - 1u) - 1u); // the power of two above tot - 1
+    const uint32_t w_shift = pw >= tot + 31u ? (pw - tot - 30u + 31u) >> 5 : 0u;
+    uint32_t w = w_halve < w_swap ? w_halve : w_swap;
+    w = w < w_shift ? w : w_shift;
+    const uint32_t lim8 = 11u * f2, lim4 = 128u * f2;
+    const uint32_t w8 = lim8 >= tot + 31u ? ((lim8 - tot - 31u) >> 5) + 1u : 0u;
+    const uint32_t w4 = lim4 >= tot + 31u ? ((lim4 - tot - 31u) >> 5) + 1u : 0u;
+    if (w != 0u && w8 != 0u)
+    {
+      cls = CLS_FAST8;
+      safe = w < w8 ? w : w8;
+    }
+    else if (w != 0u && w4 != 0u)
+    {
+      cls = CLS_FAST4;
+      safe = w < w4 ? w : w4;
+    }
+    else
+    {
+      // the general word path copes with every model event; its groups of four need tot <= 128 * f2 throughout, and a
+      // halving keeps the ratio within rounding (f2 -> (f2 + 1) / 2, tot -> about tot / 2): 100 leaves room for that
+      cls = (tot + 32u <= 100u * f2) ? CLS_GENERAL : CLS_BITS;
+      safe = 0;
+    }
+  }
+
+  // The 32 division magics of the word that a lane would code next with a fast word path (cum[0] = tot .. tot+31).
   // The kernel fetches them from LDS right after a code step, so that the (bank-conflicting, per-lane scattered) reads
   // and their latency overlap the fill and drain phases instead of heading the next word.
   DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
@@ -405,147 +542,96 @@ struct BacEncoder
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
       Mg[i] = 0x40000000u + tot * 131u + i; // diagnostic build: no table reads
 #else
-      Mg[i] = mg[i]; // past the table's end for tot > 16352: never used then (fast_ok() is false)
+      Mg[i] = mg[i]; // past the table's end for tot > 16352: never used then (no fast class)
 #endif
   }
 
-  DG_DEV bool encode_word_fast(uint32_t word, uint32_t (&Mg)[32])
+  // ---- word paths: 32 symbols, branch free ---------------------------------------------------------------------------------
+  // GENERAL = false: no model event can occur in the word (classes FAST8 / FAST4): the magics come in registers, the
+  //                  counts change only by c1 -= lps.
+  // GENERAL = true : the whole model update of bac.c:54-81 by selects; magics read from the table as the counts move.
+  // DUMP: symbols between two dumps (8 or 4).
+  // Returns 0, or -- when a carry ran past the held-back word -- the record for settle_word().
+  template <bool GENERAL, uint32_t DUMP>
+  DG_DEV uint32_t encode_word(uint32_t word, const uint32_t *magic, uint32_t (&Mg)[32])
   {
-    const uint32_t lw = mps ? ~word : word; // bit set = less probable symbol
-    const uint32_t sh = div_shift(tot);
-    uint32_t *const op0 = oring + staged * 64u;
-    uint32_t *op = op0;
-    uint32_t ovf = 0;
+    static_assert(!GENERAL || ADAPTIVE, "the static model never needs the general path");
+    static_assert(32 / DUMP <= 8, "the record of a word's hand-overs has 8 + 8 bits");
+    uint32_t took = 0, ovf = 0;
+    uint32_t mm = 0u - mps;                          // all ones when the MPS is the bit value 1
+    const uint32_t lw = GENERAL ? word : (word ^ mm); // fast: bit set = less probable symbol (the MPS cannot change)
+    const uint32_t sh_word = div_shift(tot);
+    uint32_t Mcur = GENERAL ? magic[tot] : 0u;
+    if (!GENERAL)
+    {
 #pragma unroll
-    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-      DG_MATERIALISE(Mg[i]);
+      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+        DG_MATERIALISE(Mg[i]);
+    }
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 8)
     constexpr uint32_t NSYM = 16; // diagnostic build: half the symbols per word
 #else
     constexpr uint32_t NSYM = 32;
 #endif
-    constexpr uint32_t FLUSH_EVERY = 8; // 4 costs 2.8 % more time for the same streams; overflows (redo) stay below 1e-4 per word
 #pragma unroll
     for (uint32_t i = 0; i < NSYM; i++)
     {
-      const uint32_t M = ADAPTIVE ? Mg[i] : Mg[0];
-      const uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for an LPS
-      const uint32_t Rm1 = not_hi16(A + B);
-      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 256)
-      const uint32_t x2 = mulhi32(Rm1 + 1u, M) >> sh;
-#else
-      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
-#endif
-      const uint32_t inc = select32(lm, x2, x1);
-      B = select32(lm, 0u - (A + (x1 << 16)), B);
-      A += inc << 16;
-      if (ADAPTIVE)
-        c1 -= lm; // f2++ for an LPS; tot is implicit (mg[i])
-      // output accumulator
-      add64_count_carry(W, (uint64_t)inc << wsh, pc);
-      // renormalise
-      const uint32_t k = clz32(~(A ^ B));
-      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
-      A <<= n;
-      B <<= n;
-      wsh -= n;
-      // Word hand-off, checked every FLUSH_EVERY symbols only: between checks the accumulator may hold up to 47
-      // finished bits (wsh >= 1).  A burst of more than 16 + (32 - cnt) bits inside one group would push the window
-      // out of W; wsh then wraps and the word is redone from the checkpoint (needs ~4+ bits per symbol: rare).
-      if ((i % FLUSH_EVERY) == FLUSH_EVERY - 1)
+      uint32_t M, sh, c1u = c1, totu = tot, Mnext = 0;
+      if (GENERAL)
       {
-        ovf |= wsh > 48u ? 1u : 0u;
-        if (wsh <= 16) // a word completed: hand over the one held back, hold this one back
-        {
-          const uint32_t sum = prev + pc;
-          ovf |= sum < pc ? 1u : 0u;
-          *op = sum;
-          op += 64;
-          prev = (uint32_t)(W >> 32);
-          pc = 0;
-          W <<= 32;
-          wsh += 32;
-        }
+        // the part of the model update that does not depend on this symbol: halving, next cum[0]; fetch its magic now
+        const bool halve = tot == MAX_FREQUENCY;
+        const uint32_t c1h = (c1 >> 1) + 1u;                // (f2 + 1) / 2 + 1
+        const uint32_t toth = ((tot - c1 + 1u) >> 1) + c1h; // (f1 + 1) / 2 + (f2 + 1) / 2 + 1
+        c1u = halve ? c1h : c1;                             // counts as UpdateModel sees them after :57-67
+        totu = halve ? toth : tot;
+        Mnext = magic[totu + 1u];
+        M = Mcur;
+        sh = div_shift(tot);
+      }
+      else
+      {
+        M = ADAPTIVE ? Mg[i] : Mg[0];
+        sh = sh_word;
+      }
+      const uint32_t a = (uint32_t)L;
+      uint32_t lm = (uint32_t)((int32_t)(lw << i) >> 31); // all ones for a set bit
+      if (GENERAL)
+        lm ^= mm;                                         // ... for an LPS
+      const uint32_t R = range_from_sum(a + B);               // 1 .. 65536
+      const uint32_t x1 = mulhi32(mul24(R, c1), M) >> sh;     // range * cum[1] / cum[0]   (R * c1 < 2^31)
+      const uint32_t x2 = mulhi32(R, M) >> sh;                // range * cum[2] / cum[0], cum[2] = 1
+      const uint32_t inc = select32(lm, x2, x1);
+      B = select32(lm, 0u - (a + (x1 << 16)), B);
+      L += (uint64_t)(inc << 16); // the carry out of A lands in the finished bits
+      // renormalise: A and the finished bits move together
+      const uint32_t a2 = (uint32_t)L;
+      const uint32_t k = clz32(~(a2 ^ B));
+      const uint32_t n = k + leading_ones(((a2 & B) << k) | 0x80000000u) - 1u;
+      L <<= n;
+      B <<= n;
+      if (GENERAL)
+      {
+        // the symbol-dependent part of the update (:68-80): an LPS either swaps roles (f2 == f1) or counts up
+        const uint32_t tie = (c1u - 1u == totu - c1u) ? 0xFFFFFFFFu : 0u;
+        mm ^= lm & tie;
+        c1 = c1u - (lm & ~tie);
+        tot = totu + 1u;
+        Mcur = Mnext;
+      }
+      else if (ADAPTIVE)
+        c1 -= lm; // f2++ for an LPS; tot is implicit (Mg[i])
+      if ((i % DUMP) == DUMP - 1)
+      {
+        dump();
+        hand_off_in_word(took, ovf);
       }
     }
-    const uint32_t made = (uint32_t)(op - op0) / 64u;
-    staged += made;
-    pos += made;
-    if (ADAPTIVE)
+    if (GENERAL)
+      mps = mm & 1u;
+    else if (ADAPTIVE)
       tot += 32u;
-    return ovf == 0;
-  }
-
-  // ---- general word path: 32 symbols, still branch free, with the whole model update of bac.c:54-81 --------------
-  // Used for the words during which some lane of the wave halves its frequencies, may swap MPS/LPS, or crosses a
-  // power of two in cum[0] (the division shift changes).  Costs ~1.5x the fast path instead of ~3x for encode_bit.
-  DG_DEV bool general_ok() const
-  {
-    return pos >= 1 && staged + ENC_WORD_MAX_OUT <= ORING;
-  }
-
-  DG_DEV bool encode_word_general(uint32_t word, const uint32_t *magic)
-  {
-    static_assert(ADAPTIVE, "the static model never needs the general path");
-    uint32_t *const op0 = oring + staged * 64u;
-    uint32_t *op = op0;
-    uint32_t ovf = 0;
-    uint32_t mm = 0u - mps;                       // all ones when the MPS is the bit value 1
-    uint32_t M = magic[tot];
-    constexpr uint32_t FLUSH_EVERY = 4;
-#pragma unroll
-    for (uint32_t i = 0; i < 32; i++)
-    {
-      // (1) the part of the model update that does not depend on this symbol: halving, next cum[0]; fetch its magic now
-      const bool halve = tot == MAX_FREQUENCY;
-      const uint32_t c1h = (c1 >> 1) + 1u;                        // (f2 + 1) / 2 + 1
-      const uint32_t toth = ((tot - c1 + 1u) >> 1) + c1h;         // (f1 + 1) / 2 + (f2 + 1) / 2 + 1
-      const uint32_t c1u = halve ? c1h : c1;                      // counts as UpdateModel sees them after :57-67
-      const uint32_t totu = halve ? toth : tot;
-      const uint32_t Mnext = magic[totu + 1u];
-      // (2) code the symbol with the counts as they are (same arithmetic as the fast path)
-      const uint32_t sh = div_shift(tot);
-      const uint32_t lm = (uint32_t)((int32_t)(word << i) >> 31) ^ mm; // all ones for an LPS
-      const uint32_t Rm1 = not_hi16(A + B);
-      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
-      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
-      const uint32_t inc = select32(lm, x2, x1);
-      B = select32(lm, 0u - (A + (x1 << 16)), B);
-      A += inc << 16;
-      add64_count_carry(W, (uint64_t)inc << wsh, pc);
-      const uint32_t k = clz32(~(A ^ B));
-      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
-      A <<= n;
-      B <<= n;
-      wsh -= n;
-      // (3) the symbol-dependent part of the update (:68-80): an LPS either swaps roles (f2 == f1) or counts up
-      const uint32_t tie = (c1u - 1u == totu - c1u) ? 0xFFFFFFFFu : 0u;
-      mm ^= lm & tie;
-      c1 = c1u - (lm & ~tie);
-      tot = totu + 1u;
-      M = Mnext;
-      if ((i % FLUSH_EVERY) == FLUSH_EVERY - 1)
-      {
-        ovf |= wsh > 48u ? 1u : 0u;
-        if (wsh <= 16)
-        {
-          const uint32_t sum = prev + pc;
-          ovf |= sum < pc ? 1u : 0u;
-          *op = sum;
-          op += 64;
-          prev = (uint32_t)(W >> 32);
-          pc = 0;
-          W <<= 32;
-          wsh += 32;
-        }
-      }
-    }
-    mps = mm & 1u;
-    const uint32_t made = (uint32_t)(op - op0) / 64u;
-    staged += made;
-    pos += made;
-    return ovf == 0;
+    return ovf != 0u ? took | 0x80000000u | (ovf << 16) : 0u; // nearly always 0: see settle_ripples()
   }
 };
 
@@ -602,6 +688,16 @@ DG_DEV uint32_t diff_seg_short(uint32_t u, uint32_t &last, bool &ok, bool &wide,
   const uint32_t w = ((nv << 1) ^ (uint32_t)((int32_t)nv >> 31)) + 1u;
   wide = (w >> 16) != 0u || nv == 0x80000000u;
   return w;
+}
+
+// The steady state of a 32-bit channel, as few instructions as it takes: w for samples whose difference is known to fit
+// (both below 2^31 -- the caller ORs the samples of a batch and looks at the top bit once) -- and is short (the caller ORs
+// the w of a batch and looks above bit 15 once; v = INT32_MIN cannot occur between samples below 2^31).
+DG_DEV uint32_t diff_seg_steady(uint32_t u, uint32_t &last)
+{
+  const uint32_t nv = last - u; // -v, low 32 bits
+  last = u;
+  return ((nv << 1) ^ (uint32_t)((int32_t)nv >> 31)) + 1u;
 }
 
 // ---- valuesize 33..64: samples in 64-bit containers -------------------------------------------------------------------

@@ -99,12 +99,14 @@ extern "C" __attribute__((visibility("default"))) int sim_synth(int32_t *x, size
   return 0;
 }
 
-// ---- direct test of the encoder's fast word path against its bit-at-a-time path, on random (and nasty) states -----
+// ---- direct test of the encoder's word paths against its bit-at-a-time path, on random (and nasty) states ------------
 #include <random>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 template <bool ADAPTIVE>
-static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_taken)
+static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples)
 {
   static const std::vector<uint32_t> tab = make_table();
   std::mt19937_64 rng(seed);
@@ -125,75 +127,102 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *fast_taken, int *redo_ta
       s = (uint32_t)(rng() % 0x8000u);
       en = 0x8000u + (uint32_t)(rng() % 0x8000u);
     } while (s >= 0x4000u && en < 0xC000u);
-    e.A = s << 16;
+    uint32_t A = s << 16;
     e.B = (65535u - en) << 16;
     if (rng() & 1)
     {
-      e.A |= 0x80000000u; // the "spurious" top bits left by an E3 step
+      A |= 0x80000000u; // the "spurious" top bits left by an E3 step
       e.B |= 0x80000000u;
     }
+    e.L = ((uint64_t)2 << 32) | A; // at a word boundary the finished bits have just been dumped
     if (ADAPTIVE)
     {
       do
       {
-        const unsigned kind = (unsigned)(rng() % 4);
+        const unsigned kind = (unsigned)(rng() % 5);
         e.tot = kind == 0 ? 16383u - (uint32_t)(rng() % 40u) : kind == 1 ? 3u + (uint32_t)(rng() % 70u) : 3u + (uint32_t)(rng() % 16380u);
         e.c1 = 2 + (uint32_t)(rng() % ((e.tot - 1) / 2));                 // 1 <= f2 <= f1
         if (kind == 1 || (rng() % 8) == 0)
           e.c1 = (e.tot + 1) / 2 - (uint32_t)(rng() % 2 ? 0 : (e.tot > 8 ? rng() % 3 : 0)); // f2 == f1 or nearly: swaps
+        if (kind == 4)
+          e.c1 = 2 + (uint32_t)(rng() % (1 + e.tot / 64));                // skewed counts: long codes for the rare symbol
       } while (e.c1 < 2 && e.tot < 3);
       e.mps = (uint32_t)(rng() & 1);
     }
-    const uint32_t cnt = (uint32_t)(rng() % 32u);
-    e.wsh = 48 - cnt;
-    e.W = nasty ? ~(uint64_t)0 : rng();
-    e.W &= ~(((uint64_t)1 << e.wsh) - 1);                         // nothing below the window
-    e.W = (e.W & ~((uint64_t)0xFFFF << e.wsh)) | ((uint64_t)s << e.wsh); // the window holds start (or start + 2^15)
+    e.fcnt = (uint32_t)(rng() % 32u);
+    e.F = (nasty ? ~(uint64_t)0 : rng()) & (((uint64_t)1 << e.fcnt) - 1);
     e.prev = nasty ? 0xFFFFFFFFu - (uint32_t)(rng() % 2) : (uint32_t)rng();
-    e.pc = (uint32_t)(rng() % 3);
     e.pos = 1 + (uint32_t)(rng() % 40u);
     e.drained = e.pos - 1;
     BacEncoder<ADAPTIVE> f = e;
     f.dst = buf_b.data();
     f.oring = ring_b.data();
-    const uint32_t word = (rng() % 3) ? (uint32_t)rng() : (uint32_t)(rng() & rng() & rng());
+    // the rare symbol really is rare in most words of the skewed states, frequent in the others
+    uint32_t word = (rng() % 3) ? (uint32_t)rng() : (uint32_t)(rng() & rng() & rng());
+    if ((rng() % 6) == 0)
+      word = (rng() & 1) ? 0xFFFFFFFFu : 0xFFFFFFFFu << (rng() % 32); // the rare symbol 32 times over: the most bits a word can make
+    if (e.mps)
+      word = ~word;
     // (a) bit at a time
     for (uint32_t i = 0; i < 32; i++)
       e.encode_bit((word >> (31u - i)) & 1u, tab.data());
-    // (b) fast word with checkpoint / redo, as the kernel does
-    const bool use_general = ADAPTIVE && (r & 1) && f.general_ok(); // odd rounds: the general word path
-    if (use_general || f.fast_ok())
+    // (b) the word path of the lane's class -- or, two rounds out of three, of a more general class, as happens when
+    //     another lane of the wave needs one
+    f.classify();
+    uint32_t cls = f.cls;
+    if (cls <= CLS_GENERAL && ADAPTIVE && (r % 3) == 1)
+      cls = CLS_GENERAL;
+    else if (cls <= CLS_FAST4 && (r % 3) == 2)
+      cls = CLS_FAST4;
+    if (cls == CLS_BITS)
     {
-      (*fast_taken)++;
-      const BacEncoder<ADAPTIVE> ck = f;
-      bool done;
-      uint32_t Mg[32];
-      f.fetch_magics(tab.data(), Mg);
-      if constexpr (ADAPTIVE)
-        done = use_general ? f.encode_word_general(word, tab.data()) : f.encode_word_fast(word, Mg);
-      else
-        done = f.encode_word_fast(word, Mg);
-      if (!done)
-      {
-        (*redo_taken)++;
-        f = ck;
-        for (uint32_t i = 0; i < 32; i++)
-          f.encode_bit((word >> (31u - i)) & 1u, tab.data());
-      }
-    }
-    else
       for (uint32_t i = 0; i < 32; i++)
         f.encode_bit((word >> (31u - i)) & 1u, tab.data());
-    // flush both the same way and compare everything observable (prev and pc only matter as their sum: the fast path
-    // hands words over lazily, so a carry may already sit in prev where the bit path still counts it in pc)
-    e.store_prev();
-    f.store_prev();
+    }
+    else
+    {
+      (*word_taken)++;
+      uint32_t Mg[32];
+      f.fetch_magics(tab.data(), Mg);
+      uint32_t record = 0, groups = 8;
+      if (cls == CLS_FAST8)
+      {
+        record = f.template encode_word<false, 8>(word, tab.data(), Mg);
+        groups = 4;
+      }
+      else if (cls == CLS_FAST4)
+        record = f.template encode_word<false, 4>(word, tab.data(), Mg);
+      else if constexpr (ADAPTIVE)
+        record = f.template encode_word<true, 4>(word, tab.data(), Mg);
+      if (record != 0)
+      {
+        (*ripples)++;
+        f.settle_word(record, groups);
+      }
+    }
+    // Bring both to the same representation -- a carry may still wait above F's bits where the other path has already
+    // added it to the held-back word (the same number either way) -- flush, and compare everything observable
+    for (BacEncoder<ADAPTIVE> *p : {&e, &f})
+    {
+      const uint32_t carry = (uint32_t)(p->F >> p->fcnt);
+      p->F &= ((uint64_t)1 << p->fcnt) - 1;
+      const uint32_t sum = p->prev + carry;
+      if (sum < carry)
+        p->ripple_carry_from(p->pos - 1u);
+      p->prev = sum;
+    }
     e.drain_lane();
     f.drain_lane();
-    const bool same = e.A == f.A && e.B == f.B && e.c1 == f.c1 && e.tot == f.tot && e.mps == f.mps && e.W == f.W && e.wsh == f.wsh &&
-                      (e.prev + e.pc) == (f.prev + f.pc) && e.pos == f.pos && e.drained == f.drained && e.err == f.err && buf_a == buf_b;
+    const bool same = e.L == f.L && e.B == f.B && e.c1 == f.c1 && e.tot == f.tot && e.mps == f.mps && e.F == f.F && e.fcnt == f.fcnt &&
+                      e.prev == f.prev && e.pos == f.pos && e.drained == f.drained && e.err == f.err && buf_a == buf_b;
     if (!same)
+    {
       bad++;
+      if (bad <= 6 && getenv("DEGA_SIM_VERBOSE") != nullptr)
+        fprintf(stderr, "round %d cls %u nasty %d: L %d B %d c1 %d tot %d mps %d F %d (%llx %llx) fcnt %d (%u %u) prev %d (%x %x) pos %d (%u %u) drained %d err %d buf %d\n", r, cls,
+                (int)nasty, e.L == f.L, e.B == f.B, e.c1 == f.c1, e.tot == f.tot, e.mps == f.mps, e.F == f.F, (unsigned long long)e.F, (unsigned long long)f.F,
+                e.fcnt == f.fcnt, e.fcnt, f.fcnt, e.prev == f.prev, e.prev, f.prev, e.pos == f.pos, e.pos, f.pos, e.drained == f.drained, e.err == f.err, buf_a == buf_b);
+    }
   }
   return bad;
 }

@@ -82,14 +82,19 @@ def test_synth_and_normalize_kernels(sim):
 
 
 def test_fast_word_path_equals_bit_path_on_random_and_nasty_states(sim):
-    """BacEncoder::encode_word_fast (+ checkpoint/redo) against encode_bit on random encoder states, including all-ones
-    accumulators and held-back words that overflow when a carry arrives (the 33+-pending-bits case)."""
+    """BacEncoder::encode_word (classes FAST8, FAST4, GENERAL -- also run on lanes of a cheaper class, as happens when another
+    lane of the wave needs it) against encode_bit on random encoder states: every model state (near a halving, near an
+    MPS/LPS swap, skewed counts), all-ones accumulators and held-back words that overflow when a carry arrives (the
+    33+-pending-bits case, settled after the word from the record the word path returns), and words made of the rare
+    symbol only (the most finished bits a group of symbols can make: the sentinel of the 64-bit register must not be
+    shifted out -- BacEncoder::classify's capacity precondition)."""
     sim.sim_fast_vs_slow.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for ad in (1, 0):
-        fast, redo = C.c_int(), C.c_int()
-        bad = sim.sim_fast_vs_slow(2024, 60000, ad, C.byref(fast), C.byref(redo))
-        assert bad == 0
-        assert fast.value > 30000 and redo.value > 1000  # both the fast path and the redo path were exercised
+        for seed in (2024, 5):
+            words, ripples = C.c_int(), C.c_int()
+            bad = sim.sim_fast_vs_slow(seed, 60000, ad, C.byref(words), C.byref(ripples))
+            assert bad == 0
+            assert words.value > 30000 and ripples.value > 500  # word paths and the deferred carry were both exercised
 
 
 def test_decode_kernel_logic_on_golden_sets(sim):
