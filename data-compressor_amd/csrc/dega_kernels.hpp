@@ -645,6 +645,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
 
   uint32_t Mnext[32]; // division magics of the next fast word (BacDecoder::fetch_magics), read a phase ahead
   dec.fetch_magics(tab, Mnext);
+  uint32_t pre[4] = {0, 0, 0, 0}; // the stream words the next code step starts from, read from the ring a step early
   DG_STAMP_DECL;
   for (;;)
   {
@@ -671,9 +672,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
           const BacDecoder<ADAPTIVE> checkpoint = dec;
           uint32_t bits = 0;
           if (fast)
-            done = dec.template decode_word<false>(in, tab, Mnext, bits);
+            done = dec.template decode_word<false>(in, tab, Mnext, pre, bits);
           else if constexpr (ADAPTIVE)
-            done = dec.template decode_word<true>(in, tab, Mnext, bits); // halving / swap / shift change somewhere in the wave
+            done = dec.template decode_word<true>(in, tab, Mnext, pre, bits); // halving / swap / shift change somewhere in the wave
           if (done)
           {
             sp.push(bits, 32);
@@ -710,7 +711,6 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         }
       }
     }
-    dec.fetch_magics(tab, Mnext); // for the next code step; in flight during the parse and write phases
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
     if (any_can)
     {
@@ -734,6 +734,10 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         requested = 0;
       }
     }
+    // the magics of the next code step: a burst of scattered LDS reads, in flight during the parse and write phases.
+    // LDS answers in order, so everything that has to READ the LDS and wait comes before it (the copy above) or long
+    // after it (the row writer, the next step's stream words at the end of this one)
+    dec.fetch_magics(tab, Mnext);
     DG_STAMP(5);
     // ---- phase S: parse what is there --------------------------------------------------------------------------------
     {
@@ -753,7 +757,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         };
         bool more = true;
 #pragma unroll
-        for (uint32_t k = 0; k < 6; k++)
+        for (uint32_t k = 0; k < 4; k++)
           more = take();
         DG_STAMP(2);
         while (wave_any(more))
@@ -876,6 +880,13 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       const bool low = live && !bac_done && in_loaded < total_words && in_loaded < k1 + 8u; // < 2 words' worth of slack
       if ((iter % DEC_REFILL_EVERY) == 0 || wave_any(low))
         request_refill();
+    }
+    {
+      const uint32_t kn = (uint32_t)(dec.bp >> 5);
+      pre[0] = in.raw(kn);
+      pre[1] = in.raw(kn + 1u);
+      pre[2] = in.raw(kn + 2u);
+      pre[3] = in.raw(kn + 3u);
     }
     DG_STAMP(0);
   }

@@ -827,15 +827,25 @@ struct StreamWindow
   const uint32_t *ring_col; // &ring[lane]
   uint64_t nbits;           // exact stream length
 
-  DG_DEV uint32_t word(uint32_t k) const
+  DG_DEV uint32_t raw(uint32_t k) const // word k as it sits in the ring: big-endian, not yet cut at the stream's end
+  {
+    return ring_col[(k % IRING) * 64u];
+  }
+
+  DG_DEV uint32_t cook(uint32_t raw_word, uint32_t k) const
   {
     const uint64_t first = (uint64_t)k * 32u;
-    uint32_t w = bswap32(ring_col[(k % IRING) * 64u]);
+    uint32_t w = bswap32(raw_word);
     if (first >= nbits)
       w = 0;
     else if (nbits - first < 32u)
       w &= ~(0xFFFFFFFFu >> (uint32_t)(nbits - first));
     return w;
+  }
+
+  DG_DEV uint32_t word(uint32_t k) const
+  {
+    return cook(raw(k), k);
   }
 
   // 32 stream bits starting at bit position pos (words k = pos/32 and k+1 must be staged)
@@ -980,13 +990,14 @@ struct BacDecoder
       Mg[i] = mg[i];
   }
 
+  // pre[0..3]: the ring's words bp/32 .. bp/32 + 3 as read (StreamWindow::raw) -- the kernel reads them a step early
   template <bool GENERAL, uint32_t IRING>
-  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t (&Mg)[32], uint32_t &bits_out)
+  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t (&Mg)[32], const uint32_t (&pre)[4], uint32_t &bits_out)
   {
     const uint32_t sh_fast = div_shift(tot);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
-    const uint32_t w0 = in.word(k0), w1 = in.word(k0 + 1u), w2 = in.word(k0 + 2u), w3 = in.word(k0 + 3u);
+    const uint32_t w0 = in.cook(pre[0], k0), w1 = in.cook(pre[1], k0 + 1u), w2 = in.cook(pre[2], k0 + 2u), w3 = in.cook(pre[3], k0 + 3u);
     if (!GENERAL)
     {
 #pragma unroll
@@ -1018,9 +1029,9 @@ struct BacDecoder
         M = ADAPTIVE ? Mg[i] : Mg[0];
         sh = sh_fast;
       }
-      const uint32_t Rm1 = not_hi16(A + B);
-      const uint32_t x1 = mulhi32(mul24(Rm1, c1) + c1, M) >> sh;
-      const uint32_t x2 = (uint32_t)(((uint64_t)Rm1 * M + M) >> 32) >> sh;
+      const uint32_t R = range_from_sum(A + B);           // 1 .. 65536
+      const uint32_t x1 = mulhi32(mul24(R, c1), M) >> sh; // range * cum[1] / cum[0]
+      const uint32_t x2 = mulhi32(R, M) >> sh;            // range * cum[2] / cum[0], cum[2] = 1
       const uint32_t lm = (uint32_t)((int32_t)(D - x1) >> 31); // all ones unless index 1 (D, x1 < 2^17)
       const uint32_t inc = select32(lm, x2, x1);
       B = select32(lm, 0u - (A + (x1 << 16)), B);
