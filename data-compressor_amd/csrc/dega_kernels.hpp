@@ -305,15 +305,18 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     issue_rows(0);
 
   uint32_t iter = 0;
-  uint32_t Mnext[32]; // division magics of the next fast word, see BacEncoder::fetch_magics
-  enc.fetch_magics(tab, Mnext);
-  uint32_t word = 0;  // the queued word a lane codes next, read from its ring column a step early
   DG_STAMP_DECL;
   for (;;)
   {
     DG_STAMP(7);
     // ---- phase C: one queued word (32 symbols) for every lane that has one ---------------------------------------
     const bool has = q.wr != q.rd;
+    // What a code step reads from LDS first -- the queued word and the first quarter of its division magics -- is asked
+    // for here, ahead of the ballots that choose the word path; nothing LDS is carried around the loop (a wait at the
+    // back edge would be a wait for the whole queue).
+    const uint32_t word = ring_col[(q.rd % RING) * 64u];
+    uint32_t Mg[32];
+    enc.fetch_magics_first(tab, Mg);
     const bool any_has = wave_any(has);
     DG_STAMP(2);
     if (any_has)
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
       if (!wave_any(cls != CLS_FAST8))
       {
         if (has)
-          record = enc.template encode_word<false, 8>(word, tab, Mnext);
+          record = enc.template encode_word<false, 8>(word, tab, Mg);
         DG_STAMP(3);
       }
       else
@@ -349,10 +352,10 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
           else if (any_general)
           {
             if constexpr (ADAPTIVE)
-              record = enc.template encode_word<true, 4>(word, tab, Mnext);
+              record = enc.template encode_word<true, 4>(word, tab, Mg);
           }
           else
-            record = enc.template encode_word<false, 4>(word, tab, Mnext);
+            record = enc.template encode_word<false, 4>(word, tab, Mg);
         }
         DG_STAMP(4);
       }
@@ -367,7 +370,6 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
         enc.safe -= enc.safe != 0u ? 1u : 0u;
       }
     }
-    enc.fetch_magics(tab, Mnext); // for the next code step; in flight during fill and drain
     // ---- phase F: the same ROWS rows for every lane ----------------------------------------------------------
     const bool room = (q.wr - q.rd) + FILL_WORDS <= RING;
     const bool fill = t < a.T && wave_all(room);
@@ -490,8 +492,6 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     }
     else if (!any_has)
       break; // all rows consumed and every queue drained
-    // the word of the next code step: read now, needed a drain and a loop top later
-    word = ring_col[(q.rd % RING) * 64u];
     // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
     // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
     iter++;

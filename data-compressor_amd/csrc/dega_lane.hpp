@@ -28,6 +28,7 @@
 // would sit in the per-symbol dependency chain)
 #define DG_MATERIALISE(x) asm volatile("" : "+v"(x))
 #endif
+#define DG_COMPILER_BARRIER() asm volatile("" ::: "memory")
 
 namespace dg
 {
@@ -534,6 +535,15 @@ struct BacEncoder
   // The 32 division magics of the word that a lane would code next with a fast word path (cum[0] = tot .. tot+31).
   // The kernel fetches them from LDS right after a code step, so that the (bank-conflicting, per-lane scattered) reads
   // and their latency overlap the fill and drain phases instead of heading the next word.
+  // the first quarter (see encode_word); all a static model ever needs
+  DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const
+  {
+    const uint32_t *const mg = magic + tot;
+#pragma unroll
+    for (uint32_t i = 0; i < (ADAPTIVE ? 8u : 1u); i++)
+      Mg[i] = mg[i];
+  }
+
   DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
     const uint32_t *const mg = magic + tot;
@@ -561,13 +571,13 @@ struct BacEncoder
     uint32_t mm = 0u - mps;                          // all ones when the MPS is the bit value 1
     const uint32_t lw = GENERAL ? word : (word ^ mm); // fast: bit set = less probable symbol (the MPS cannot change)
     const uint32_t sh_word = div_shift(tot);
+    const uint32_t tot_word = tot;
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
-    if (!GENERAL)
-    {
-#pragma unroll
-      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-        DG_MATERIALISE(Mg[i]);
-    }
+    // The 32 division magics of a fast word are scattered, bank-conflicting LDS reads: all at once they take a few hundred
+    // cycles to land, and whoever needs an LDS answer meanwhile waits for the lot (LDS answers in order; the compiler
+    // waits for "all outstanding").  So they come in quarters: Mg[0..7] are fetched by the caller a little ahead of the
+    // word (fetch_magics_first), each further quarter here, eight symbols before its first use -- landed by then, and
+    // never more than four reads in the queue.
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 8)
     constexpr uint32_t NSYM = 16; // diagnostic build: half the symbols per word
 #else
@@ -625,6 +635,15 @@ struct BacEncoder
       {
         dump();
         hand_off_in_word(took, ovf);
+      }
+      if (!GENERAL && ADAPTIVE && (i == 0u || i == 8u || i == 16u))
+      {
+        DG_COMPILER_BARRIER(); // keeps the quarters where they are (the scheduler would gather them at the top)
+        const uint32_t *const mq = magic + tot_word + i + 8u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++)
+          Mg[i + 8u + k] = mq[k];
+        DG_COMPILER_BARRIER();
       }
     }
     if (GENERAL)

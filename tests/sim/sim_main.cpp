@@ -183,7 +183,7 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
     {
       (*word_taken)++;
       uint32_t Mg[32];
-      f.fetch_magics(tab.data(), Mg);
+      f.fetch_magics_first(tab.data(), Mg);
       uint32_t record = 0, groups = 8;
       if (cls == CLS_FAST8)
       {
