@@ -643,15 +643,20 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
   };
   request_refill();
 
-  uint32_t Mnext[32]; // division magics of the next fast word (BacDecoder::fetch_magics), read a phase ahead
-  dec.fetch_magics(tab, Mnext);
-  uint32_t pre[4] = {0, 0, 0, 0}; // the stream words the next code step starts from, read from the ring a step early
   DG_STAMP_DECL;
   for (;;)
   {
     DG_STAMP(7);
     // ---- phase C ---------------------------------------------------------------------------------------------------
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
+    // what the code step reads from LDS first: the four stream words it starts from and the first quarter of its
+    // division magics (the rest follow inside the word path); nothing LDS is carried around the loop
+    uint32_t pre[4], Mnext[32];
+    pre[0] = in.raw(k0);
+    pre[1] = in.raw(k0 + 1u);
+    pre[2] = in.raw(k0 + 2u);
+    pre[3] = in.raw(k0 + 3u);
+    dec.fetch_magics_first(tab, Mnext);
     const uint32_t need_words = k0 + 4u < total_words ? k0 + 4u : total_words; // words the next 32 symbols may touch
     const bool input_ok = in_loaded >= need_words;
     if (live && !started && input_ok)
@@ -734,10 +739,6 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
         requested = 0;
       }
     }
-    // the magics of the next code step: a burst of scattered LDS reads, in flight during the parse and write phases.
-    // LDS answers in order, so everything that has to READ the LDS and wait comes before it (the copy above) or long
-    // after it (the row writer, the next step's stream words at the end of this one)
-    dec.fetch_magics(tab, Mnext);
     DG_STAMP(5);
     // ---- phase S: parse what is there --------------------------------------------------------------------------------
     {
@@ -880,13 +881,6 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       const bool low = live && !bac_done && in_loaded < total_words && in_loaded < k1 + 8u; // < 2 words' worth of slack
       if ((iter % DEC_REFILL_EVERY) == 0 || wave_any(low))
         request_refill();
-    }
-    {
-      const uint32_t kn = (uint32_t)(dec.bp >> 5);
-      pre[0] = in.raw(kn);
-      pre[1] = in.raw(kn + 1u);
-      pre[2] = in.raw(kn + 2u);
-      pre[3] = in.raw(kn + 3u);
     }
     DG_STAMP(0);
   }

@@ -1001,11 +1001,11 @@ struct BacDecoder
   // GENERAL = false: no model event (halving, MPS/LPS swap, division-shift change) can occur in the word (fast_ok()).
   // GENERAL = true : the whole model update of bac.c:54-81 by selects, as in BacEncoder::encode_word_general.
   // as BacEncoder::fetch_magics: the kernel issues these reads a phase early
-  DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
+  DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const // as BacEncoder::fetch_magics_first
   {
     const uint32_t *const mg = magic + tot;
 #pragma unroll
-    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
+    for (uint32_t i = 0; i < (ADAPTIVE ? 8u : 1u); i++)
       Mg[i] = mg[i];
   }
 
@@ -1017,12 +1017,7 @@ struct BacDecoder
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
     const uint32_t w0 = in.cook(pre[0], k0), w1 = in.cook(pre[1], k0 + 1u), w2 = in.cook(pre[2], k0 + 2u), w3 = in.cook(pre[3], k0 + 3u);
-    if (!GENERAL)
-    {
-#pragma unroll
-      for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
-        DG_MATERIALISE(Mg[i]);
-    }
+    const uint32_t tot_word = tot;
     uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2:w3
     uint32_t off_group = off;
     uint32_t ahead = off ? (w0 << off) | (w1 >> (32u - off)) : w0; // next 32 stream bits, left aligned
@@ -1076,6 +1071,15 @@ struct BacDecoder
       D = (uint32_t)(da >> 32);
       ahead = (uint32_t)da;
       off += n;
+      if (!GENERAL && ADAPTIVE && (i == 0u || i == 8u || i == 16u)) // the next quarter of the magics (see BacEncoder::encode_word)
+      {
+        DG_COMPILER_BARRIER();
+        const uint32_t *const mq = magic + tot_word + i + 8u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++)
+          Mg[i + 8u + k] = mq[k];
+        DG_COMPILER_BARRIER();
+      }
       if ((i & 7u) == 7u) // rebuild the look-ahead from the staged words (8 symbols rarely take more than 32 bits: else redo)
       {
         bad |= (off - off_group > 32u || off > 95u) ? 1u : 0u;
