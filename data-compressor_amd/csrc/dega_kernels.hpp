@@ -168,7 +168,6 @@ constexpr uint32_t WAVES = BLOCK / 64;
 
 constexpr uint32_t ENC_RING = 32;                               // queued words per lane (LDS: 4 KiB per wave)
 constexpr uint32_t ENC_ROWS = 8;                                // rows per fill batch
-constexpr uint32_t ENC_DRAIN_EVERY = 4;                            // code steps between output drains
 constexpr uint32_t ENC_FILL_WORDS = (31 + 65 * ENC_ROWS) / 32;  // most words a batch can add (65-bit worst-case codewords)
 static_assert(ENC_FILL_WORDS < ENC_RING, "ring too small");
 
@@ -304,7 +303,6 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   if (a.T > 0)
     issue_rows(0);
 
-  uint32_t iter = 0;
   DG_STAMP_DECL;
   for (;;)
   {
@@ -492,34 +490,47 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     }
     else if (!any_has)
       break; // all rows consumed and every queue drained
-    // ---- drain: staged words -> slabs, all lanes in lockstep, four words (16 bytes) per lane and store ---------------
-    // Every ENC_DRAIN_EVERY-th step, or as soon as a column could not take another word's worth of output.
-    iter++;
-    constexpr uint32_t DRAIN_EVERY = ORING >= 32 ? 2 * ENC_DRAIN_EVERY : ENC_DRAIN_EVERY; // as rarely as the column allows
-    if ((iter % DRAIN_EVERY) == 0 || wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
+    // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------------
+    // As soon as some column could not take another word path's worth of output, every lane that holds a whole 64-byte
+    // group stores it: four 16-byte stores to consecutive addresses, so a lane's stores fill whole 64-byte segments of
+    // its slab (16-byte stores scattered in time left 128-byte lines half written: 1.6 x the stream bytes went to HBM).
+    if (wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
     {
+      constexpr uint32_t GROUP = 16;
       uint32_t base = 0; // first staged slot not yet stored
-      while (wave_any(enc.staged - base >= 4u))
+      while (wave_any(enc.staged - base >= GROUP))
       {
-        if (enc.staged - base >= 4u)
+        if (enc.staged - base >= GROUP)
         {
           const uint32_t *const sl = enc.oring + base * 64u;
+          uint32_t g[GROUP];
+#pragma unroll
+          for (uint32_t k = 0; k < GROUP; k++)
+            g[k] = sl[k * 64u];
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 1)
-          if (sl[0] == 0x12345u) // diagnostic build: no output stores
+          if (g[0] == 0x12345u) // diagnostic build: no output stores
 #endif
-            enc.put_group(enc.drained + base, sl[0], sl[64], sl[128], sl[192]);
-          base += 4;
+          {
+#pragma unroll
+            for (uint32_t k = 0; k < GROUP; k += 4)
+              enc.put_group(enc.drained + base + k, g[k], g[k + 1], g[k + 2], g[k + 3]);
+          }
+          base += GROUP;
         }
       }
-      // move the 0..3 left-over words to the front of the column
+      // move the left-over words (fewer than a group) to the front of the column
       const uint32_t rest = enc.staged - base;
-      const uint32_t *const sl = enc.oring + base * 64u;
-      const uint32_t r0 = sl[0], r1 = sl[64], r2 = sl[128];
-      if (base > 0 && rest > 0)
+      if (base > 0)
       {
-        enc.oring[0] = r0;
-        enc.oring[64] = r1;
-        enc.oring[128] = r2;
+        const uint32_t *const sl = enc.oring + base * 64u;
+        uint32_t g[GROUP - 1];
+#pragma unroll
+        for (uint32_t k = 0; k < GROUP - 1; k++)
+          g[k] = sl[(k < ORING - GROUP ? k : 0u) * 64u]; // at most ORING - GROUP words can be left over
+#pragma unroll
+        for (uint32_t k = 0; k < GROUP - 1 && k < ORING - GROUP; k++)
+          if (k < rest)
+            enc.oring[k * 64u] = g[k];
       }
       enc.drained += base;
       enc.staged = rest;
