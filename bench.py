@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 # The model behind roofline.issue_bound_ms: VALU instructions of the unrolled symbol step (ISA count of the
 # shipped kernel, csrc/Makefile `asm`), cycles per wave instruction on a SIMD that holds one wave
 # (profiles/r01_ubench_issue_cost.txt) and the shader clock under this load.
-ISSUE_INSTR_PER_SYMBOL = 29
+ISSUE_INSTR_PER_SYMBOL = 27.5  # 24 per symbol + (10 dump + 18 hand-over) per 8 symbols
 ISSUE_CYCLES_PER_INSTR = 4.3
 SHADER_CLOCK_HZ = 2.25e9
 
@@ -337,7 +337,7 @@ def run_dega(env, args):
             sym = seg_symbols_per_sample(xs)
             issue_ms = T * sym * ISSUE_INSTR_PER_SYMBOL * ISSUE_CYCLES_PER_INSTR / SHADER_CLOCK_HZ * 1e3
             res["roofline"].update({"issue_bound_ms": round(issue_ms, 2), "issue_bound_frac": round(issue_ms / kernel_ms, 4) if kernel_ms > 0 else None,
-                                    "issue_bound_model": "%d samples x %.2f coded symbols x %d VALU instructions x %.1f cycles / %.2f GHz, one wave per SIMD"
+                                    "issue_bound_model": "%d samples x %.2f coded symbols x %.1f VALU instructions x %.1f cycles / %.2f GHz, one wave per SIMD"
                                                          % (T, sym, ISSUE_INSTR_PER_SYMBOL, ISSUE_CYCLES_PER_INSTR, SHADER_CLOCK_HZ / 1e9)})
             if env.pool is not None:
                 res["cpu_all_cores"] = cpu_all_cores(env.pool, env.ncores, xs)
