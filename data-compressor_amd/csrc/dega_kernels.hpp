@@ -634,8 +634,9 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
   bool started = false;      // StartDecoding done
   bool bac_done = !live;     // EOF symbol seen (or error)
   bool lane_final = !live;   // nothing more will come out of this lane
-  size_t t_lane = 0;         // samples produced
-  size_t rows_stored = 0;    // wave uniform
+  uint32_t t_lane = 0;       // samples produced (T <= 2^25)
+  uint32_t rows_stored = 0;  // wave uniform
+  const uint32_t T32 = (uint32_t)a.T;
   int32_t lane_err = OK;
   uint32_t iter = 0;
 
@@ -759,9 +760,10 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       //     follow-up passes 2 each
       if constexpr (!W64)
       {
+        const uint32_t t_limit = rows_stored + SRING < T32 ? rows_stored + SRING : T32; // room in the sample ring, samples asked for
         auto take = [&]() {
           uint32_t sample;
-          const bool allowed = !lane_final && t_lane - rows_stored < SRING && t_lane < a.T;
+          const bool allowed = !lane_final && t_lane < t_limit;
           const bool took = sp.template take_short<NARROW>(allowed, sample);
           sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
           t_lane += took ? 1u : 0u;
@@ -798,7 +800,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
               r = sp.template next<NARROW>(bac_done, sample);
             if (r == 1)
             {
-              if (t_lane >= a.T)
+              if (t_lane >= T32)
               {
                 if (lane_err == OK)
                   lane_err = a.out_count != nullptr ? ERR_MEMORY : ERR_INVALID_FORMAT; // more samples than room / than asked for
@@ -819,7 +821,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
             {
               if (r < 0 && lane_err == OK)
                 lane_err = r;
-              if (r == 2 && t_lane != a.T && a.out_count == nullptr && lane_err == OK)
+              if (r == 2 && t_lane != T32 && a.out_count == nullptr && lane_err == OK)
                 lane_err = ERR_INVALID_FORMAT; // fewer samples than the caller asked for
               lane_final = true;
               stalled = true;
@@ -840,6 +842,10 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
     // every lane has is stored.  (With a reported count, rows past the longest channel of the wave are not written.)
     for (;;)
     {
+      // nearly always: the next four rows are there for every lane, or not yet -- one ballot answers for all four
+      const bool four = rows_stored + 4u <= T32 && wave_all(lane_final || t_lane >= rows_stored + 4u);
+      if (!four && !wave_all(lane_final))
+        break; // lanes are still producing: the rows wait until four are whole (a lane may run SRING samples ahead)
       uint32_t cand[4], cand_hi[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++)
@@ -852,8 +858,8 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++)
       {
-        const size_t row = rows_stored + k;
-        if (wrote == k && row < a.T && wave_all(lane_final || t_lane > row) && (a.out_count == nullptr || wave_any(t_lane > row)))
+        const uint32_t row = rows_stored + k;
+        if (wrote == k && row < T32 && (four || wave_all(lane_final || t_lane > row)) && (a.out_count == nullptr || wave_any(t_lane > row)))
         {
           if constexpr (F32OUT)
           {
@@ -866,15 +872,15 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
             else
               v = denormalize_value((float)(NARROW ? (int32_t)(cand[k] << sp.vshift) >> sp.vshift : (int32_t)cand[k]), a.factor);
             if (live)
-              reinterpret_cast<float *>(a.x)[row * a.ld + c] = t_lane > row ? v : 0.0f;
+              reinterpret_cast<float *>(a.x)[(size_t)row * a.ld + c] = t_lane > row ? v : 0.0f;
           }
           else if constexpr (W64)
           {
             if (live)
-              reinterpret_cast<int64_t *>(a.x)[row * a.ld + c] = t_lane > row ? (int64_t)(((uint64_t)cand_hi[k] << 32) | cand[k]) : 0;
+              reinterpret_cast<int64_t *>(a.x)[(size_t)row * a.ld + c] = t_lane > row ? (int64_t)(((uint64_t)cand_hi[k] << 32) | cand[k]) : 0;
           }
           else if (live)
-            a.x[row * a.ld + c] = t_lane > row ? (int32_t)(a.big_endian ? bswap32(cand[k]) : cand[k]) : 0;
+            a.x[(size_t)row * a.ld + c] = t_lane > row ? (int32_t)(a.big_endian ? bswap32(cand[k]) : cand[k]) : 0;
           wrote = k + 1;
         }
       }
@@ -882,7 +888,7 @@ __global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a
       if (wrote < 4)
         break;
     }
-    if (wave_all(lane_final) && (rows_stored >= a.T || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
+    if (wave_all(lane_final) && (rows_stored >= T32 || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
     DG_STAMP(6);
     // ---- phase R ------------------------------------------------------------------------------------------------------

@@ -154,6 +154,13 @@ DG_DEV uint32_t range_from_sum(uint32_t x)
 #endif
 }
 
+// The same written in C++, for the decoder: hipcc's SDWA peephole folds the shift into the subtraction and, unlike behind
+// inline asm, adds no wait state (measured: the decoder is 0.4 % faster this way, the encoder 1.4 % slower)
+DG_DEV uint32_t range_from_sum_plain(uint32_t x)
+{
+  return 0x10000u - (x >> 16);
+}
+
 // Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic[t]) >> shift(t)  with
 // magic = ceil(2^(30+L) / t), L = ceil(log2 t), shift = L - 2: the error term n*(magic*t - 2^(30+L)) / (t * 2^(30+L)) is
 // below 2^-L <= 1/t, so the floor cannot move.  This replaces the two 64-bit divisions per symbol of bac.c:110-111
@@ -1043,7 +1050,7 @@ struct BacDecoder
         M = ADAPTIVE ? Mg[i] : Mg[0];
         sh = sh_fast;
       }
-      const uint32_t R = range_from_sum(A + B);           // 1 .. 65536
+      const uint32_t R = range_from_sum_plain(A + B);     // 1 .. 65536
       const uint32_t x1 = mulhi32(mul24(R, c1), M) >> sh; // range * cum[1] / cum[0]
       const uint32_t x2 = mulhi32(R, M) >> sh;            // range * cum[2] / cum[0], cum[2] = 1
       const uint32_t lm = (uint32_t)((int32_t)(D - x1) >> 31); // all ones unless index 1 (D, x1 < 2^17)

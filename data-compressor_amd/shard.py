@@ -1,8 +1,9 @@
-"""Multi-GPU sharding of the DEGA path: channels are independent (every stream starts from last_value = 0 and a fresh
-model: DCLib/src/diff.c:11, bac.c:150), so N GPUs = N disjoint channel ranges and NO data-path collective.  This module
-holds the two host-side pieces that remain: the channel partition, and the gather that concatenates the ranks' packed
-streams in channel order (offset table = prefix sum of byte sizes).  Backend agnostic: RCCL ("nccl") on
-GPUs, gloo in the CPU tests."""
+"""Multi-PROCESS sharding helpers (one process per GPU, the layout bench.py is launched in): channels are independent
+(every stream starts from last_value = 0 and a fresh model: DCLib/src/diff.c:11, bac.c:150), so N GPUs = N disjoint channel
+ranges and NO data-path collective.  Inside ONE process the product does all of this itself (dega_hip_group_* of
+include/dega_hip.h: one context and one host thread per device, host-side concatenate); when every GPU has a process of its
+own, what remains is the channel partition and bringing the ranks' packed streams together on one HOST: gather_streams
+moves the streams to host memory first and gathers them there (gloo group) -- never a device-side collective."""
 
 
 def channel_range(rank, world, total_channels):
@@ -21,14 +22,19 @@ def pack_streams(streams, bits):
 
 
 def gather_streams(packed, bits, group=None, dst=0):
-    """Collect every rank's (packed bytes, bit lengths) on `dst` in rank (= channel) order.
-    packed: 1-D uint8 tensor, bits: 1-D int64 tensor (both on the device the backend wants).
-    Returns (packed_all, bits_all, offsets) on dst -- offsets[c] = first byte of channel c -- and (None, None, None) elsewhere."""
+    """Collect every rank's (packed bytes, bit lengths) on `dst`'s HOST in rank (= channel) order.
+    packed: 1-D uint8 tensor, bits: 1-D int64 tensor; device tensors are copied to host memory first, and `group` must be
+    a process group that carries host tensors (gloo): the streams travel host to host, no RCCL / xGMI traffic.
+    Returns (packed_all, bits_all, offsets) as host tensors on dst -- offsets[c] = first byte of channel c -- and
+    (None, None, None) elsewhere."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if "gloo" not in str(dist.get_backend(group)).lower():
+        raise RuntimeError("gather_streams concatenates on the host: pass a gloo process group (dist.new_group(backend='gloo'))")
+    packed, bits = packed.cpu(), bits.cpu()
     dev = packed.device
     meta = torch.tensor([packed.numel(), bits.numel()], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
