@@ -26,99 +26,14 @@
 namespace dg
 {
 
-#if !defined(DEGA_SIM)
-DG_DEV bool wave_any(bool p)
-{
-  return __any((int)p) != 0;
-}
-DG_DEV bool wave_all(bool p)
-{
-  return __all((int)p) != 0;
-}
-DG_DEV uint32_t wave_min_u32(uint32_t v) // butterfly over the 64 lanes
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1)
-  {
-    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-DG_DEV uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1)
-  {
-    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-#endif
-
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-// diagnostic build: per-wave cycle totals per section of the encode loop (s_memtime), dumped over out_bits[] / err[]
-#define DG_STAMP_DECL uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define DG_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_sum[k] += now_ - stamp_t0; stamp_cnt[k]++; stamp_t0 = now_; } while (0)
-#else
-#define DG_STAMP_DECL
-#define DG_STAMP(k)
-#endif
-
-#if !defined(DEGA_SIM)
-// One dword per lane from global memory straight into LDS (LDS-DMA): lane l's dword lands at lds_row[l].
-// lds_row must be wave uniform.  Completion is NOT tracked by hipcc: wait with wait_vector_memory() before reading.
-DG_DEV void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t /*lane*/)
-{
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                   (__attribute__((address_space(3))) void *)lds_row, 4, 0, 0);
-}
-// Four dwords per lane (16-byte aligned source): lane l's 16 bytes land at lds_base + 16*l.
-DG_DEV void dma_x4_to_lds(const int32_t *src, uint32_t *lds_base, uint32_t /*lane*/)
-{
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
-}
-DG_DEV void wait_vector_memory()
-{
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-#else
-inline void dma_x4_to_lds(const int32_t *src, uint32_t *lds_base, uint32_t lane)
-{
-  for (uint32_t k = 0; k < 4; k++)
-    lds_base[lane * 4 + k] = (uint32_t)src[k];
-}
-inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
-{
-  lds_row[lane] = (uint32_t)*src;
-}
-inline void wait_vector_memory() {}
-#endif
-
 // lo = -(float)2^(valuesize-1), hi = (float)(2^(valuesize-1) - 1) as the host's C compiler rounds them (normalize.c:21;
 // hi rounds up to 2^(valuesize-1) from valuesize 26 on), mask = the low valuesize bits written (normalize.c:24)
 DG_DEV bool normalize_value(float v, float factor, int32_t &out, float lo = -2147483648.0f, float hi = 2147483648.0f, uint32_t mask = 0xFFFFFFFFu)
 {
-#if defined(DEGA_SIM)
-  volatile float prod;
   if (v > 0.0f)
-  {
-    prod = v * factor;
-    v = prod + 0.5f;
-  }
+    v = fadd_once(fmul_once(v, factor), 0.5f); // normalize.c:17-18: two operations, two roundings
   else if (v < 0.0f)
-  {
-    prod = v * factor;
-    v = prod - 0.5f;
-  }
-#else
-  if (v > 0.0f)
-    v = __fadd_rn(__fmul_rn(v, factor), 0.5f); // normalize.c:17-18
-  else if (v < 0.0f)
-    v = __fsub_rn(__fmul_rn(v, factor), 0.5f); // :19-20
-#endif
+    v = fadd_once(fmul_once(v, factor), -0.5f); // :19-20
   const bool ok = !(v < lo || v > hi); // :21 -- for valuesize 32 (float)(2^31-1) is 2^31, so exactly 2^31 passes
   out = (int32_t)((v >= 2147483648.0f ? 0x80000000u : (uint32_t)(int32_t)v) & mask); // :23-24 (int64) truncation, low valuesize bits
   return ok;
@@ -130,24 +45,10 @@ DG_DEV bool normalize_value(float v, float factor, int32_t &out, float lo = -214
 // cvttss2si does: to the "integer indefinite" 0x8000000000000000.
 DG_DEV bool normalize_value64(float v, float factor, uint64_t &out, float lo, float hi, uint64_t mask)
 {
-#if defined(DEGA_SIM)
-  volatile float prod;
   if (v > 0.0f)
-  {
-    prod = v * factor;
-    v = prod + 0.5f;
-  }
+    v = fadd_once(fmul_once(v, factor), 0.5f);
   else if (v < 0.0f)
-  {
-    prod = v * factor;
-    v = prod - 0.5f;
-  }
-#else
-  if (v > 0.0f)
-    v = __fadd_rn(__fmul_rn(v, factor), 0.5f);
-  else if (v < 0.0f)
-    v = __fsub_rn(__fmul_rn(v, factor), 0.5f);
-#endif
+    v = fadd_once(fmul_once(v, factor), -0.5f);
   const bool ok = !(v < lo || v > hi);
   const bool big = v >= 9223372036854775808.0f || v < -9223372036854775808.0f || v != v;
   out = (big ? 0x8000000000000000ull : (uint64_t)(int64_t)v) & mask;
@@ -156,11 +57,7 @@ DG_DEV bool normalize_value64(float v, float factor, uint64_t &out, float lo, fl
 
 DG_DEV float denormalize_value(float n, float factor) // normalize.c:38: true IEEE division, no reciprocal
 {
-#if defined(DEGA_SIM)
-  return n / factor;
-#else
-  return __fdiv_rn(n, factor);
-#endif
+  return fdiv_once(n, factor);
 }
 
 constexpr uint32_t BLOCK = 256;

@@ -17,18 +17,7 @@
 // precondition that is looked at once per many words, and a bit-at-a-time slow path that handles everything.
 #pragma once
 
-#include <stdint.h>
-
-#if defined(DEGA_SIM)
-#define DG_DEV inline
-#define DG_MATERIALISE(x) ((void)0)
-#else
-#define DG_DEV __device__ __forceinline__
-// the value must be in its register here: stops hipcc from sinking a load down to its first use (where its latency
-// would sit in the per-symbol dependency chain)
-#define DG_MATERIALISE(x) asm volatile("" : "+v"(x))
-#endif
-#define DG_COMPILER_BARRIER() asm volatile("" ::: "memory")
+#include "dega_intrinsics.hpp"
 
 namespace dg
 {
@@ -40,126 +29,6 @@ constexpr int32_t ERR_MEMORY = -6;
 
 constexpr uint32_t MAX_FREQUENCY = 16383; // bac.c:27
 constexpr uint32_t DIV_TABLE_SIZE = 16384;
-
-DG_DEV uint32_t clz32(uint32_t x) // x != 0
-{
-  return (uint32_t)__builtin_clz(x);
-}
-
-DG_DEV uint32_t mulhi32(uint32_t a, uint32_t b)
-{
-#if defined(DEGA_SIM)
-  return (uint32_t)(((uint64_t)a * b) >> 32);
-#else
-  return __umulhi(a, b);
-#endif
-}
-
-DG_DEV uint32_t mul24(uint32_t a, uint32_t b) // both < 2^24
-{
-#if defined(DEGA_SIM)
-  return a * b;
-#else
-  return (uint32_t)__umul24(a, b);
-#endif
-}
-
-DG_DEV uint32_t bswap32(uint32_t x)
-{
-  return __builtin_bswap32(x);
-}
-
-#if defined(DEGA_SIM)
-inline float __uint_as_float(uint32_t u)
-{
-  float f;
-  __builtin_memcpy(&f, &u, 4);
-  return f;
-}
-#endif
-
-DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // mask is all ones or all zeros
-{
-#if defined(DEGA_SIM)
-  return (if_set & mask) | (if_clear & ~mask);
-#else
-  uint32_t r; // one v_bfi_b32; left to itself hipcc rebuilds the select from a compare, two v_cndmask and and/or
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(if_set), "v"(if_clear));
-  return r;
-#endif
-}
-
-// Number of leading one bits of x, for x with bit 31 set and not all ones (v_ffbh_i32 counts the bits equal to the sign).
-DG_DEV uint32_t leading_ones(uint32_t x)
-{
-#if defined(DEGA_SIM)
-  return (uint32_t)__builtin_clz(~x);
-#else
-  uint32_t r;
-  asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-#endif
-}
-
-// W += add (64 bit), carries += carry out -- three chained adds
-DG_DEV void add64_count_carry(uint64_t &W, uint64_t add, uint32_t &carries)
-{
-#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 128))
-  const uint64_t nw = W + add;
-  carries += nw < add ? 1u : 0u;
-  W = nw;
-#else
-  uint32_t lo = (uint32_t)W, hi = (uint32_t)(W >> 32);
-  asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
-      : "+v"(lo), "+v"(hi), "+v"(carries)
-      : "v"((uint32_t)add), "v"((uint32_t)(add >> 32))
-      : "vcc");
-  W = ((uint64_t)hi << 32) | lo;
-#endif
-}
-
-// (acc << 1) | (x >> 31) in one instruction (funnel shift)
-DG_DEV uint32_t shift_in_msb(uint32_t acc, uint32_t x)
-{
-#if defined(DEGA_SIM)
-  return (acc << 1) | (x >> 31);
-#else
-  return __builtin_amdgcn_alignbit(acc, x, 31);
-#endif
-}
-
-// (~x) >> 16 in one instruction (SDWA: NOT of the high word, written zero-extended)
-DG_DEV uint32_t not_hi16(uint32_t x)
-{
-#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 64))
-  return (~x) >> 16;
-#else
-  uint32_t r;
-  asm("v_not_b32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(x));
-  return r;
-#endif
-}
-
-// range = 65536 - (x >> 16) for x = A + B in one instruction (SDWA: the high word of x as the subtrahend); x = 0 is the
-// full range 65536, which is why this is not simply -x >> 16
-DG_DEV uint32_t range_from_sum(uint32_t x)
-{
-#if defined(DEGA_SIM) || (defined(DEGA_DIAG) && (DEGA_DIAG & 64))
-  return 0x10000u - (x >> 16);
-#else
-  uint32_t r;
-  const uint32_t full = 0x10000u;
-  asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(full), "v"(x));
-  return r;
-#endif
-}
-
-// The same written in C++, for the decoder: hipcc's SDWA peephole folds the shift into the subtraction and, unlike behind
-// inline asm, adds no wait state (measured: the decoder is 0.4 % faster this way, the encoder 1.4 % slower)
-DG_DEV uint32_t range_from_sum_plain(uint32_t x)
-{
-  return 0x10000u - (x >> 16);
-}
 
 // Exact floor(n / t) for 0 <= n < 2^30, 3 <= t <= 16383 as  mulhi(n, magic[t]) >> shift(t)  with
 // magic = ceil(2^(30+L) / t), L = ceil(log2 t), shift = L - 2: the error term n*(magic*t - 2^(30+L)) / (t * 2^(30+L)) is
@@ -281,16 +150,7 @@ struct BacEncoder
   {
     if (index + 4u <= cap_words)
     {
-#if defined(DEGA_SIM)
-      dst[index] = bswap32(w0);
-      dst[index + 1] = bswap32(w1);
-      dst[index + 2] = bswap32(w2);
-      dst[index + 3] = bswap32(w3);
-#else
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-      u32x4 v = {bswap32(w0), bswap32(w1), bswap32(w2), bswap32(w3)};
-      *reinterpret_cast<u32x4 *>(dst + index) = v;
-#endif
+      store_x4(dst + index, bswap32(w0), bswap32(w1), bswap32(w2), bswap32(w3));
     }
     else
     {
