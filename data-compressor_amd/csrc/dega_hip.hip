@@ -355,12 +355,9 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
 }
 
 template <bool AD, bool NARROW, bool F32>
-static void decode_launch(bool eight_waves, size_t C, hipStream_t s, const DecodeArgs &a)
+static void decode_launch(size_t C, hipStream_t s, const DecodeArgs &a)
 {
-  if (eight_waves)
-    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, 8, false, F32>), dim3((unsigned)((C + 511) / 512)), dim3(512), 0, s, a);
-  else
-    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, WAVES, false, F32>), dim3((unsigned)((C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+  hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32>), dim3((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS)), dim3(DEC_BLOCK), 0, s, a);
 }
 
 static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, const Shape &j, size_t batch_C, void *x,
@@ -388,23 +385,23 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
   a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
   a.factor = j.factor;
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
-  const bool eight = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
+  (void)batch_C; // one workgroup shape for every batch size: pairs of waves, two per SIMD (dega_kernels.hpp)
   {
     LaunchTimer lt(ctx, 1, s);
     if (vs > 32)
     {
-      const dim3 grid((unsigned)((j.C + BLOCK - 1) / BLOCK));
+      const dim3 grid((unsigned)((j.C + DEC_CHANNELS - 1) / DEC_CHANNELS));
       if (f32)
       {
         if (ad)
-          hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true, true>), grid, dim3(BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_decode_kernel<true, false, true, true>), grid, dim3(DEC_BLOCK), 0, s, a);
         else
-          hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true, true>), grid, dim3(BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_decode_kernel<false, false, true, true>), grid, dim3(DEC_BLOCK), 0, s, a);
       }
       else if (ad)
-        hipLaunchKernelGGL((dega_decode_kernel<true, false, 4, true, false>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_decode_kernel<true, false, true, false>), grid, dim3(DEC_BLOCK), 0, s, a);
       else
-        hipLaunchKernelGGL((dega_decode_kernel<false, false, 4, true, false>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_decode_kernel<false, false, true, false>), grid, dim3(DEC_BLOCK), 0, s, a);
     }
     else
     {
@@ -412,14 +409,14 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
       const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
       switch (sel)
       {
-        case 0: decode_launch<false, false, false>(eight, j.C, s, a); break;
-        case 1: decode_launch<false, false, true>(eight, j.C, s, a); break;
-        case 2: decode_launch<false, true, false>(eight, j.C, s, a); break;
-        case 3: decode_launch<false, true, true>(eight, j.C, s, a); break;
-        case 4: decode_launch<true, false, false>(eight, j.C, s, a); break;
-        case 5: decode_launch<true, false, true>(eight, j.C, s, a); break;
-        case 6: decode_launch<true, true, false>(eight, j.C, s, a); break;
-        default: decode_launch<true, true, true>(eight, j.C, s, a); break;
+        case 0: decode_launch<false, false, false>(j.C, s, a); break;
+        case 1: decode_launch<false, false, true>(j.C, s, a); break;
+        case 2: decode_launch<false, true, false>(j.C, s, a); break;
+        case 3: decode_launch<false, true, true>(j.C, s, a); break;
+        case 4: decode_launch<true, false, false>(j.C, s, a); break;
+        case 5: decode_launch<true, false, true>(j.C, s, a); break;
+        case 6: decode_launch<true, true, false>(j.C, s, a); break;
+        default: decode_launch<true, true, true>(j.C, s, a); break;
       }
     }
   }

@@ -7,6 +7,9 @@
 #pragma once
 
 #include <stdint.h>
+#if defined(DEGA_SIM)
+#include <sched.h>
+#endif
 
 #if defined(DEGA_SIM)
 #define DG_DEV inline
@@ -183,6 +186,57 @@ inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
 }
 inline void wait_vector_memory() {}
 #endif
+
+// ---- two waves of one workgroup talking through LDS (the paired-wave kernels: one wave codes, its partner parses) -----
+// A wave's LDS instructions execute in the order it issued them, so "write the data, then write the counter" needs no
+// fence in hardware; the wrappers only stop the COMPILER from reordering or caching the accesses.  The emulator's lanes
+// are OS threads: release / acquire there.
+DG_DEV void peer_store(uint32_t *lds_word, uint32_t v)
+{
+#if defined(DEGA_SIM)
+  __atomic_store_n(lds_word, v, __ATOMIC_RELEASE);
+#else
+  DG_COMPILER_BARRIER();
+  *reinterpret_cast<volatile uint32_t *>(lds_word) = v;
+  DG_COMPILER_BARRIER();
+#endif
+}
+DG_DEV uint32_t peer_load(const uint32_t *lds_word)
+{
+#if defined(DEGA_SIM)
+  return __atomic_load_n(lds_word, __ATOMIC_ACQUIRE);
+#else
+  DG_COMPILER_BARRIER();
+  const uint32_t v = *reinterpret_cast<const volatile uint32_t *>(lds_word);
+  DG_COMPILER_BARRIER();
+  return v;
+#endif
+}
+// nothing to do until the partner has moved: leave the SIMD's issue slots to it for about 64 * n cycles
+template <int N>
+DG_DEV void wave_sleep()
+{
+#if defined(DEGA_SIM)
+  sched_yield();
+#else
+  __builtin_amdgcn_s_sleep(N);
+#endif
+}
+template <int P>
+DG_DEV void wave_priority() // 0 (default) .. 3: which of a SIMD's waves issues first when both are ready
+{
+#if !defined(DEGA_SIM)
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
+DG_DEV uint32_t wave_uniform(uint32_t v) // v is the same in every lane: tell the compiler (scalar register)
+{
+#if defined(DEGA_SIM)
+  return v;
+#else
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
 
 // float32 arithmetic with exactly one IEEE rounding per operation and no contraction into an FMA (normalize.c's
 // value * factor +- 0.5 and value / factor as the reference's compiler emits them: mulss, addss/subss, divss)

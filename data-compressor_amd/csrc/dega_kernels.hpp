@@ -454,19 +454,32 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
 }
 
 // =====================================================================================================================
-// Decode (bac -> seg -> prefix sum fused).  Mirror image of the encoder's structure:
-//   phase C ("code", word lockstep)   every lane that has input staged and room for 32 more decoded bits decodes 32
-//                                     symbols -> one word of seg bits into its column of an LDS ring.
-//   phase S ("samples")               lanes parse as many complete exp-Golomb codewords as they hold, add them up
-//                                     (diff.c:32-35) and park the samples in their column of an LDS sample ring.
-//   phase W ("write", row lockstep)   rows that every lane has produced are stored, one coalesced 256-byte segment per
-//                                     wave and row.
-//   phase R ("refill")                every few steps each lane with room fetches the next 4 words of its stream
-//                                     (LDS-DMA into a staging row; copied to the lane's own ring slots after the wait).
+// Decode (bac -> seg -> prefix sum fused), by PAIRS of waves.
+//
+// A channel's decoder is serial and instruction bound, and a batch of 64 Ki channels is only one wave per SIMD: whatever
+// that wave waits for (LDS, the row stores, its own ballots and branches) leaves the SIMD idle.  So the work of 64
+// channels is split between two waves that the CU places on the same SIMD (wave w and wave w + 4 of the workgroup):
+//   the CODING wave   owns the compressed stream: LDS-DMA of the slab words into the lane's ring, the arithmetic
+//                     decoder -- 32 symbols per step, word lockstep, as in the encoder -- and hands every decoded 32-bit
+//                     word of seg bits to its partner through a small LDS ring;
+//   the PARSING wave  takes the words, cuts them into exp-Golomb codewords, adds the differences up (diff.c:32-35), parks
+//                     the samples in the lane's column of an LDS sample ring and stores every row that all 64 lanes have
+//                     produced as one coalesced 256-byte segment.
+// The two run concurrently, each filling the issue slots the other leaves empty.  They talk through one published
+// word per lane and direction (counters modulo 2^16, see peer_store / peer_load); a wave with nothing to do sleeps.
 // =====================================================================================================================
-constexpr uint32_t DEC_IRING = 16; // staged stream words per lane
-constexpr uint32_t DEC_SRING = 16; // decoded samples per lane
-constexpr uint32_t DEC_REFILL_EVERY = 4;
+constexpr uint32_t DEC_IRING = 16;                 // staged stream words per lane
+constexpr uint32_t DEC_BRING = 8;                  // decoded words in flight between the two waves, per lane
+constexpr uint32_t DEC_SRING = 16;                 // decoded samples per lane (the 64-bit variants)
+constexpr uint32_t DEC_PAIRS = 4;                  // pairs of waves per workgroup
+constexpr uint32_t DEC_BLOCK = DEC_PAIRS * 128;    // threads per workgroup
+constexpr uint32_t DEC_CHANNELS = DEC_PAIRS * 64;  // channels per workgroup
+
+// what the coding wave publishes: words handed over so far (mod 2^16) | valid bits of the LAST word if it is a partial
+// one << 16 | no more words will come << 24 | the stream was found invalid << 25
+constexpr uint32_t DEC_PUB_DONE = 1u << 24, DEC_PUB_BAD = 1u << 25;
+// what the parsing wave publishes: words taken so far (mod 2^16) | the lane needs no more words << 16
+constexpr uint32_t DEC_PUB_FINAL = 1u << 16;
 
 struct DecodeArgs
 {
@@ -483,334 +496,451 @@ struct DecodeArgs
   float factor;        // F32OUT variants: Denormalize (normalize.c:29-41) fused into the row write; x is float [T][ld]
 };
 
-// NW = waves per workgroup: 4 (one per SIMD) for batches of up to 64 Ki channels, 8 for larger ones -- two waves per SIMD
-// fill the issue slots a lone wave leaves empty while it waits on LDS or memory (the LDS budget allows it: 138 KiB)
-// W64: valuesize 33..64 -- a.x is int64 [T][ld]; the parser is SegParser64 (no short-codeword passes), samples take two
-// LDS slots.  Instantiated with NW = 4.
-// F32OUT: the decoded value, read back as valuesize bits sign extended (normalize.c:36-37), leaves as (float)n / factor
-// (:38, IEEE division) -- float32 rows [T][ld] also for W64, no integer intermediate in HBM.
-template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, bool W64 = false, bool F32OUT = false>
-__global__ void __launch_bounds__(NW * 64) dega_decode_kernel(const DecodeArgs a)
+struct alignas(16) DecodeQuad
 {
-  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  // decoded samples a lane may run ahead of the slowest lane of its wave before it has to wait for the row writer: the
-  // 4-wave shape has the LDS for 64 (151 KiB per workgroup; 16 -> 64 is -5 % time), the others stay at 16
-  constexpr uint32_t SRING = NW == 4 && !W64 ? 64 : DEC_SRING;
-  constexpr uint32_t PER_WAVE = (DEC_IRING + 4 + (W64 ? 2 : 1) * (SRING + 1)) * 64; // + a spare sample slot
-  __shared__ uint32_t lds[TAB_WORDS + NW * PER_WAVE];
-  uint32_t *const tab = lds;
-  load_div_table<ADAPTIVE>(tab, a.div_magic);
+  uint32_t w[4];
+};
 
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  const size_t c = (size_t)blockIdx.x * (NW * 64u) + threadIdx.x;
-  const bool live = c < a.C;
-  uint32_t *const wave_lds = lds + TAB_WORDS + wave * PER_WAVE;
-  uint32_t *const iring = wave_lds + lane;                               // staged stream words
-  uint32_t *const stage_wave = wave_lds + DEC_IRING * 64;                // DMA landing rows (wave uniform)
-  uint32_t *const sring = wave_lds + (DEC_IRING + 4) * 64 + lane;        // decoded samples
-  uint32_t *const sring_hi = sring + (SRING + 1) * 64;               // their high dwords (W64 only)
+// ---- the coding wave -------------------------------------------------------------------------------------------------
+// pair_lds: [DEC_IRING rows: the lane's stream words][4 rows: DMA landing area][DEC_BRING rows: decoded words]
+//           [1 row: published by this wave][1 row: published by the partner] ...
+template <bool ADAPTIVE>
+DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_t *pair_lds, uint32_t lane, size_t c, bool live)
+{
+  uint32_t *const iring = pair_lds + lane;
+  uint32_t *const stage_wave = pair_lds + DEC_IRING * 64;
+  uint32_t *const bring = pair_lds + (DEC_IRING + 4) * 64 + lane;
+  uint32_t *const pub_mine = pair_lds + (DEC_IRING + 4 + DEC_BRING) * 64 + lane;
+  const uint32_t *const pub_peer = pub_mine + 64;
 
   const uint32_t cap_words = (uint32_t)(a.cap / 4);
   const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
   const uint64_t nbits = live ? a.in_bits[c] : 0;
-  const uint32_t total_words = (uint32_t)((nbits + 31) / 32) < cap_words ? (uint32_t)((nbits + 31) / 32) : cap_words;
+  StreamTail tail;
+  tail.init(nbits, cap_words);
   const uint32_t max_seg_bits = (uint32_t)a.T * 65u; // no valid stream of T samples decodes to more bits (T <= 2^25)
+  // 16 bytes per lane and DMA instruction when the slabs allow it (a lane's words are 16-byte aligned, and a group of
+  // four never leaves the slab); else four single words
+  const bool quads = (a.cap % 16u) == 0u && (((size_t)a.in) % 16u) == 0u;
 
   StreamWindow<DEC_IRING> in;
   in.ring_col = iring;
-  in.nbits = nbits;
   BacDecoder<ADAPTIVE> dec;
   dec.init();
-  typename std::conditional<W64, SegParser64, SegParser>::type sp;
-  sp.init(NARROW || W64 ? a.valuesize : 32u);
-  uint32_t seg_bits = 0; // seg bits decoded so far
 
-  uint32_t in_loaded = 0;    // stream words staged so far (a multiple of 4 until the end)
-  uint32_t requested = 0;    // words requested by the DMA in flight (0 or up to 4)
-  bool started = false;      // StartDecoding done
-  bool bac_done = !live;     // EOF symbol seen (or error)
-  bool lane_final = !live;   // nothing more will come out of this lane
-  uint32_t t_lane = 0;       // samples produced (T <= 2^25)
-  uint32_t rows_stored = 0;  // wave uniform
-  const uint32_t T32 = (uint32_t)a.T;
-  int32_t lane_err = OK;
-  uint32_t iter = 0;
+  uint32_t in_loaded = 0;   // stream words staged so far (a multiple of 4; beyond the stream: zeros)
+  bool requested = false;   // a group of 4 is on its way (or due as zeros)
+  bool started = false;     // StartDecoding done
+  bool bac_done = !live;    // EOF symbol seen, error, or the partner wants no more
+  uint32_t seg_bits = 0;    // seg bits decoded so far
+  uint32_t wr = 0;          // words handed over
+  uint32_t acc = 0, nacc = 0; // a word in the making, bit by bit (see below)
+  uint32_t pub_flags = 0;
+  if (!wave_any(live))
+    return; // a wave past the last channel
 
-  auto request_refill = [&]() // 4 more words for every lane that has ring room for them (and stream left)
+  auto request_refill = [&]() // 4 more words for every lane that has ring room for them
   {
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
-    const bool want = live && requested == 0 && in_loaded < total_words && in_loaded + 4u - k0 <= DEC_IRING;
-    if (want)
+    const bool want = live && !requested && !bac_done && in_loaded + 4u - k0 <= DEC_IRING;
+    if (want && in_loaded < tail.words)
     {
+      if (quads)
+        dma_x4_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded), stage_wave, lane);
+      else
+      {
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++)
-        if (in_loaded + j < total_words)
-          dma_row_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded + j), stage_wave + j * 64u, lane);
-      requested = total_words - in_loaded < 4u ? total_words - in_loaded : 4u;
+        for (uint32_t j = 0; j < 4; j++)
+          if (in_loaded + j < cap_words)
+            dma_row_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded + j), stage_wave + j * 64u, lane);
+      }
     }
+    requested = requested || want;
   };
   request_refill();
 
-  DG_STAMP_DECL;
   for (;;)
   {
-    DG_STAMP(7);
-    // ---- phase C ---------------------------------------------------------------------------------------------------
+    // ---- what the step reads from LDS first: four stream words, the first quarter of the division magics, and how far
+    //      the partner has come; nothing LDS is carried around the loop
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
-    // what the code step reads from LDS first: the four stream words it starts from and the first quarter of its
-    // division magics (the rest follow inside the word path); nothing LDS is carried around the loop
     uint32_t pre[4], Mnext[32];
-    pre[0] = in.raw(k0);
-    pre[1] = in.raw(k0 + 1u);
-    pre[2] = in.raw(k0 + 2u);
-    pre[3] = in.raw(k0 + 3u);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++)
+      pre[j] = in.word(k0 + j);
     dec.fetch_magics_first(tab, Mnext);
-    const uint32_t need_words = k0 + 4u < total_words ? k0 + 4u : total_words; // words the next 32 symbols may touch
-    const bool input_ok = in_loaded >= need_words;
+    const uint32_t peer = peer_load(pub_peer);
+    const bool input_ok = in_loaded >= k0 + 4u;
     if (live && !started && input_ok)
     {
       dec.start(in);
       started = true;
     }
-    const bool can = live && started && !bac_done && input_ok && sp.has_room();
-    const bool can_slow = can;
-    const bool any_can = wave_any(can_slow);
-    if (any_can)
+    if ((peer & DEC_PUB_FINAL) != 0u)
+      bac_done = true; // the parser has all it wants from this channel (or has given it up)
+    const bool room = ((wr - peer) & 0xFFFFu) < DEC_BRING;
+    const bool can = live && started && !bac_done && room;
+    const bool can_word = can && input_ok && nacc == 0u;
+    if (wave_any(can))
     {
-      const bool fast = wave_all(!can_slow || (can && dec.fast_ok()));
-      if (can_slow)
+      bool done = false;
+      if (wave_any(can_word))
       {
-        bool done = false;
+        const bool fast = wave_all(!can_word || dec.fast_ok());
+        if (can_word)
         {
           const BacDecoder<ADAPTIVE> checkpoint = dec;
           uint32_t bits = 0;
           if (fast)
-            done = dec.template decode_word<false>(in, tab, Mnext, pre, bits);
+            done = dec.template decode_word<false>(tab, Mnext, pre, bits);
           else if constexpr (ADAPTIVE)
-            done = dec.template decode_word<true>(in, tab, Mnext, pre, bits); // halving / swap / shift change somewhere in the wave
+            done = dec.template decode_word<true>(tab, Mnext, pre, bits); // halving / swap / shift change somewhere in the wave
           if (done)
           {
-            sp.push(bits, 32);
+            bring[(wr % DEC_BRING) * 64u] = bits;
+            wr++;
             seg_bits += 32;
           }
           else
             dec = checkpoint;
         }
-        if (!done)
+      }
+      // Bit by bit -- the EOF symbol is in this word, or its symbols take more stream bits than the word path looks
+      // ahead.  A word made this way may take several steps: a symbol is decoded only while the two stream words it may
+      // touch are staged (32 rare symbols in a row can take 300 bits and more).
+      const bool slow = can && !done && (nacc != 0u || can_word);
+      if (wave_any(slow))
+      {
+        if (slow)
         {
-          // bit by bit: up to 32 symbols, stops at the EOF symbol; fills the current (possibly partial) word
 #pragma unroll 1
-          for (uint32_t i = 0; i < 32 && !bac_done; i++)
+          while (nacc < 32u && !bac_done && in_loaded >= (uint32_t)(dec.bp >> 5) + 2u)
           {
             const uint32_t r = dec.decode_bit(in, tab);
             if (r == 2)
             {
               bac_done = true;
-              if (dec.bp > nbits + 14u && lane_err == OK)
-                lane_err = ERR_INVALID_FORMAT; // more than 14 phantom bits (bac.c:171-186)
+              if (dec.bp > nbits + 14u)
+                pub_flags |= DEC_PUB_BAD; // more than 14 phantom bits (bac.c:171-186)
             }
             else
             {
-              sp.push(r, 1);
+              acc = (acc << 1) | r;
+              nacc++;
               seg_bits++;
             }
           }
           if (!bac_done && seg_bits > max_seg_bits)
           {
             bac_done = true; // runaway stream: cannot be T samples
-            if (lane_err == OK)
-              lane_err = ERR_INVALID_FORMAT;
+            pub_flags |= DEC_PUB_BAD;
+          }
+          if (nacc == 32u || (bac_done && nacc != 0u))
+          {
+            bring[(wr % DEC_BRING) * 64u] = acc << ((32u - nacc) & 31u);
+            pub_flags = (pub_flags & ~(31u << 16)) | ((nacc & 31u) << 16);
+            wr++;
+            acc = 0;
+            nacc = 0;
           }
         }
       }
+      peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u));
     }
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-    if (any_can)
+    else
     {
-      if (wave_all(!can_slow || (can && dec.fast_ok())))
-        DG_STAMP(3);
-      else
-        DG_STAMP(4);
+      peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u));
+      if (wave_all(bac_done))
+        break;
+      wave_sleep<1>(); // waiting for the partner (ring full) or for stream words
     }
-#endif
-    // ---- the DMA issued at the end of the previous step has landed: move the words to the lane's own ring slots -----
-    if (wave_any(requested > 0)) // (delaying this by a step, to give the DMA more time, starves lanes: slower)
+    // ---- the DMA issued at the end of the previous step has landed: cook the words into the lane's own ring slots ----
+    if (wave_any(requested))
     {
       wait_vector_memory();
-      if (requested > 0)
+      if (requested)
       {
+        uint32_t s[4];
+        if (quads)
+        {
+          const DecodeQuad q = *reinterpret_cast<const DecodeQuad *>(stage_wave + lane * 4u);
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++)
+            s[j] = q.w[j];
+        }
+        else
+        {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++)
+            s[j] = stage_wave[j * 64u + lane];
+        }
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++)
-          if (j < requested)
-            iring[((in_loaded + j) % DEC_IRING) * 64u] = stage_wave[j * 64u + lane];
-        in_loaded += requested;
-        requested = 0;
+          iring[((in_loaded + j) % DEC_IRING) * 64u] = tail.cook(s[j], in_loaded + j);
+        in_loaded += 4;
+        requested = false;
       }
     }
-    DG_STAMP(5);
-    // ---- phase S: parse what is there --------------------------------------------------------------------------------
+    // ---- refill: when some lane is down to two steps' worth, every lane with room asks for its next four words ----------
     {
-      // (1) the steady state, branch free: short codewords off the top of the window; a lane that cannot take one writes
-      //     to a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data and the window
-      //     up to 64 bits, so the first pass takes up to 6 -- which is all there is for nearly every wave -- and the rare
-      //     follow-up passes 2 each
-      if constexpr (!W64)
+      const uint32_t k1 = (uint32_t)(dec.bp >> 5);
+      const bool low = live && !bac_done && in_loaded < k1 + 8u;
+      if (wave_any(low))
+        request_refill();
+    }
+  }
+  wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
+}
+
+// ---- the parsing wave ------------------------------------------------------------------------------------------------
+template <bool NARROW, bool W64, bool F32OUT, uint32_t SRING>
+DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_t lane, size_t c, bool live, size_t c_wave0)
+{
+  const uint32_t *const bring = pair_lds + (DEC_IRING + 4) * 64 + lane;
+  const uint32_t *const pub_peer = pair_lds + (DEC_IRING + 4 + DEC_BRING) * 64 + lane;
+  uint32_t *const pub_mine = pair_lds + (DEC_IRING + 4 + DEC_BRING + 1) * 64 + lane;
+  uint32_t *const sring = pair_lds + (DEC_IRING + 4 + DEC_BRING + 2) * 64 + lane; // decoded samples (+ a spare slot)
+  uint32_t *const sring_hi = sring + (SRING + 1) * 64;                            // their high dwords (W64 only)
+
+  typename std::conditional<W64, SegParser64, SegParser>::type sp;
+  sp.init(NARROW || W64 ? a.valuesize : 32u);
+  uint32_t rd = 0;          // words taken from the partner
+  bool final_in = !live;    // the partner is done and every word of it has been taken
+  bool lane_final = !live;  // nothing more will come out of this lane
+  uint32_t t_lane = 0;      // samples produced (T <= 2^25)
+  uint32_t rows_stored = 0; // wave uniform
+  const uint32_t T32 = (uint32_t)a.T;
+  int32_t lane_err = OK;
+  bool carry_over = true;   // the previous pass changed something a further pass could build on
+  const bool full_wave = c_wave0 + 64u <= a.C;
+  if (!wave_any(live))
+    return; // a wave past the last channel
+
+  // one decoded value -> memory, in the form the variant writes (rows past a failed channel's last sample: zeros)
+  auto store_value = [&](uint32_t row, uint32_t lo, uint32_t hi, bool valid) {
+    if constexpr (F32OUT)
+    {
+      float v;
+      if constexpr (W64)
       {
-        const uint32_t t_limit = rows_stored + SRING < T32 ? rows_stored + SRING : T32; // room in the sample ring, samples asked for
-        auto take = [&]() {
-          uint32_t sample;
-          const bool allowed = !lane_final && t_lane < t_limit;
-          const bool took = sp.template take_short<NARROW>(allowed, sample);
-          sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
-          t_lane += took ? 1u : 0u;
-          return took;
-        };
-        bool more = true;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-          more = take();
-        DG_STAMP(2);
-        while (wave_any(more))
-        {
-          more = take();
-          more = take();
-          DG_STAMP(2);
-        }
+        const uint32_t sh64 = 64u - a.valuesize; // 0..31
+        v = denormalize_value((float)((int64_t)((((uint64_t)hi << 32) | lo) << sh64) >> sh64), a.factor);
       }
-      // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;
-      //     entered only by lanes that cannot simply wait for more bits
-      bool stalled = lane_final || t_lane - rows_stored >= SRING || !(bac_done || sp.cnt >= 32u || sp.pending());
-      while (wave_any(!stalled))
+      else
+        v = denormalize_value((float)(NARROW ? (int32_t)(lo << sp.vshift) >> sp.vshift : (int32_t)lo), a.factor);
+      reinterpret_cast<float *>(a.x)[(size_t)row * a.ld + c] = valid ? v : 0.0f;
+    }
+    else if constexpr (W64)
+      reinterpret_cast<int64_t *>(a.x)[(size_t)row * a.ld + c] = valid ? (int64_t)(((uint64_t)hi << 32) | lo) : 0;
+    else
+      a.x[(size_t)row * a.ld + c] = valid ? (int32_t)(a.big_endian ? bswap32(lo) : lo) : 0;
+  };
+
+  for (;;)
+  {
+    // ---- the next decoded word, if the partner has one and the window has room for it ---------------------------------
+    const uint32_t peer = peer_load(pub_peer);
+    const uint32_t avail = (peer - rd) & 0xFFFFu;
+    const bool peer_done = (peer & DEC_PUB_DONE) != 0u;
+    const bool got = !lane_final && avail != 0u && sp.has_room();
+    {
+      const uint32_t word = bring[(rd % DEC_BRING) * 64u];
+      const uint32_t part = (peer >> 16) & 31u;
+      const uint32_t n = (peer_done && avail == 1u && part != 0u) ? part : 32u; // only the last word can be a partial one
+      sp.push_word(got ? word : 0u, got ? n : 0u);
+      rd += got ? 1u : 0u;
+    }
+    final_in = !live || (peer_done && ((peer - rd) & 0xFFFFu) == 0u);
+    peer_store(pub_mine, (rd & 0xFFFFu) | (lane_final ? DEC_PUB_FINAL : 0u));
+    if (!wave_any(got || (final_in && !lane_final)) && !carry_over)
+    {
+      wave_sleep<2>();
+      continue;
+    }
+    if (final_in && (peer & DEC_PUB_BAD) != 0u && lane_err == OK)
+      lane_err = ERR_INVALID_FORMAT; // found by the arithmetic decoder: phantom bits, runaway stream
+    const uint32_t t_before = t_lane, rows_before = rows_stored;
+    const bool final_before = lane_final;
+
+    // ---- parse what is there -------------------------------------------------------------------------------------------
+    bool more = false;
+    // (1) the steady state, branch free: short codewords off the top of the window; a lane that cannot take one writes to
+    //     a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data: four takes, then
+    //     two more for as long as some lane's window would not have room for its next word
+    if constexpr (!W64)
+    {
+      const uint32_t t_limit = rows_stored + SRING < T32 ? rows_stored + SRING : T32; // room in the sample ring, samples asked for
+      auto take = [&]() {
+        uint32_t sample;
+        const bool allowed = !lane_final && t_lane < t_limit;
+        const bool took = sp.template take_short<NARROW>(allowed, sample);
+        sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
+        t_lane += took ? 1u : 0u;
+        return took;
+      };
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        more = take();
+      while (wave_any(more && (!sp.has_room() || final_in)))
       {
-        if (!stalled)
+        more = take();
+        more = take();
+      }
+    }
+    // (2) everything else -- codewords of 33+ bits, the end of the stream, too many samples -- one codeword per pass;
+    //     entered only by lanes that cannot simply wait for more bits
+    bool stalled = lane_final || more || t_lane - rows_stored >= SRING || !(final_in || sp.cnt >= 32u || sp.pending());
+    while (wave_any(!stalled))
+    {
+      if (!stalled)
+      {
+        if (t_lane - rows_stored >= SRING)
+          stalled = true; // sample ring full until rows are written
+        else
         {
-          if (t_lane - rows_stored >= SRING)
-            stalled = true; // sample ring full until rows are written
+          typename std::conditional<W64, uint64_t, uint32_t>::type sample = 0;
+          int32_t r;
+          if constexpr (W64)
+            r = sp.next(final_in, sample);
           else
+            r = sp.template next<NARROW>(final_in, sample);
+          if (r == 1)
           {
-            typename std::conditional<W64, uint64_t, uint32_t>::type sample = 0;
-            int32_t r;
-            if constexpr (W64)
-              r = sp.next(bac_done, sample);
-            else
-              r = sp.template next<NARROW>(bac_done, sample);
-            if (r == 1)
+            if (t_lane >= T32)
             {
-              if (t_lane >= T32)
-              {
-                if (lane_err == OK)
-                  lane_err = a.out_count != nullptr ? ERR_MEMORY : ERR_INVALID_FORMAT; // more samples than room / than asked for
-                lane_final = true;
-                stalled = true;
-              }
-              else
-              {
-                sring[(t_lane % SRING) * 64u] = (uint32_t)sample;
-                if constexpr (W64)
-                  sring_hi[(t_lane % SRING) * 64u] = (uint32_t)((uint64_t)sample >> 32);
-                t_lane++;
-              }
-            }
-            else if (r == 0)
-              stalled = true; // needs more decoded bits
-            else
-            {
-              if (r < 0 && lane_err == OK)
-                lane_err = r;
-              if (r == 2 && t_lane != T32 && a.out_count == nullptr && lane_err == OK)
-                lane_err = ERR_INVALID_FORMAT; // fewer samples than the caller asked for
+              if (lane_err == OK)
+                lane_err = a.out_count != nullptr ? ERR_MEMORY : ERR_INVALID_FORMAT; // more samples than room / than asked for
               lane_final = true;
               stalled = true;
             }
+            else
+            {
+              sring[(t_lane % SRING) * 64u] = (uint32_t)sample;
+              if constexpr (W64)
+                sring_hi[(t_lane % SRING) * 64u] = (uint32_t)((uint64_t)sample >> 32);
+              t_lane++;
+            }
+          }
+          else if (r == 0)
+            stalled = true; // needs more decoded bits
+          else
+          {
+            if (r < 0 && lane_err == OK)
+              lane_err = r;
+            if (r == 2 && t_lane != T32 && a.out_count == nullptr && lane_err == OK)
+              lane_err = ERR_INVALID_FORMAT; // fewer samples than the caller asked for
+            lane_final = true;
+            stalled = true;
           }
         }
       }
-      if (lane_err != OK)
-      {
-        lane_final = true; // a failed channel stops here; its remaining rows are written as zeros
-        bac_done = true;
-      }
     }
-    DG_STAMP(1);
-    // ---- phase W: rows every lane has ----------------------------------------------------------------------------------
-    // (with a reported count, rows past the longest channel of the wave are not written at all)
-    // Up to 4 rows per pass: the 4 candidate samples are read from the ring at once (one LDS wait), then each row that
-    // every lane has is stored.  (With a reported count, rows past the longest channel of the wave are not written.)
-    for (;;)
+    if (lane_err != OK)
+      lane_final = true; // a failed channel stops here; its remaining rows are written as zeros
+
+    // ---- rows every lane has -----------------------------------------------------------------------------------------------
+    // The steady state: all 64 channels exist, none has ended, and the next eight rows are there for every lane -- one
+    // ballot, eight samples out of the ring, eight 256-byte stores.
+    while (full_wave && rows_stored + 8u <= T32 && wave_all(t_lane >= rows_stored + 8u))
     {
-      // nearly always: the next four rows are there for every lane, or not yet -- one ballot answers for all four
-      const bool four = rows_stored + 4u <= T32 && wave_all(lane_final || t_lane >= rows_stored + 4u);
-      if (!four && !wave_all(lane_final))
-        break; // lanes are still producing: the rows wait until four are whole (a lane may run SRING samples ahead)
-      uint32_t cand[4], cand_hi[4] = {0, 0, 0, 0};
+      uint32_t cand[8], cand_hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
+      for (uint32_t k = 0; k < 8; k++)
       {
         cand[k] = sring[((rows_stored + k) % SRING) * 64u];
         if constexpr (W64)
           cand_hi[k] = sring_hi[((rows_stored + k) % SRING) * 64u];
       }
-      uint32_t wrote = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
+      for (uint32_t k = 0; k < 8; k++)
+        store_value(rows_stored + k, cand[k], cand_hi[k], true);
+      rows_stored += 8;
+    }
+    // The ends -- a partial wave, channels that have finished or failed, the last rows, a reported count (then rows past
+    // the longest channel of the wave are not written at all): up to 4 rows per pass, each checked on its own.
+    if (!full_wave || wave_any(lane_final) || rows_stored + 8u > T32)
+    {
+      for (;;)
       {
-        const uint32_t row = rows_stored + k;
-        if (wrote == k && row < T32 && (four || wave_all(lane_final || t_lane > row)) && (a.out_count == nullptr || wave_any(t_lane > row)))
+        const bool four = rows_stored + 4u <= T32 && wave_all(lane_final || t_lane >= rows_stored + 4u);
+        if (!four && !wave_all(lane_final))
+          break; // lanes are still producing: the rows wait until four are whole (a lane may run SRING samples ahead)
+        uint32_t cand[4], cand_hi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
         {
-          if constexpr (F32OUT)
-          {
-            float v;
-            if constexpr (W64)
-            {
-              const uint32_t sh64 = 64u - a.valuesize; // 0..31
-              v = denormalize_value((float)((int64_t)((((uint64_t)cand_hi[k] << 32) | cand[k]) << sh64) >> sh64), a.factor);
-            }
-            else
-              v = denormalize_value((float)(NARROW ? (int32_t)(cand[k] << sp.vshift) >> sp.vshift : (int32_t)cand[k]), a.factor);
-            if (live)
-              reinterpret_cast<float *>(a.x)[(size_t)row * a.ld + c] = t_lane > row ? v : 0.0f;
-          }
-          else if constexpr (W64)
-          {
-            if (live)
-              reinterpret_cast<int64_t *>(a.x)[(size_t)row * a.ld + c] = t_lane > row ? (int64_t)(((uint64_t)cand_hi[k] << 32) | cand[k]) : 0;
-          }
-          else if (live)
-            a.x[(size_t)row * a.ld + c] = t_lane > row ? (int32_t)(a.big_endian ? bswap32(cand[k]) : cand[k]) : 0;
-          wrote = k + 1;
+          cand[k] = sring[((rows_stored + k) % SRING) * 64u];
+          if constexpr (W64)
+            cand_hi[k] = sring_hi[((rows_stored + k) % SRING) * 64u];
         }
+        uint32_t wrote = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+        {
+          const uint32_t row = rows_stored + k;
+          if (wrote == k && row < T32 && (four || wave_all(lane_final || t_lane > row)) && (a.out_count == nullptr || wave_any(t_lane > row)))
+          {
+            if (live)
+              store_value(row, cand[k], cand_hi[k], t_lane > row);
+            wrote = k + 1;
+          }
+        }
+        rows_stored += wrote;
+        if (wrote < 4)
+          break;
       }
-      rows_stored += wrote;
-      if (wrote < 4)
-        break;
     }
     if (wave_all(lane_final) && (rows_stored >= T32 || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
-    DG_STAMP(6);
-    // ---- phase R ------------------------------------------------------------------------------------------------------
-    iter++;
-    {
-      const uint32_t k1 = (uint32_t)(dec.bp >> 5);
-      const bool low = live && !bac_done && in_loaded < total_words && in_loaded < k1 + 8u; // < 2 words' worth of slack
-      if ((iter % DEC_REFILL_EVERY) == 0 || wave_any(low))
-        request_refill();
-    }
-    DG_STAMP(0);
+    carry_over = rows_stored != rows_before || wave_any(t_lane != t_before || lane_final != final_before);
   }
+  peer_store(pub_mine, (rd & 0xFFFFu) | DEC_PUB_FINAL);
   if (live)
   {
     a.err[c] = lane_err;
     if (a.out_count != nullptr)
       a.out_count[c] = t_lane;
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-    uint64_t *dbg = const_cast<uint64_t *>(a.in_bits); // diagnostic build only: dump the stamps over in_bits
-    if (lane < 8)
-      dbg[c] = stamp_sum[lane];
-    else if (lane < 16)
-      dbg[c] = stamp_cnt[lane - 8];
-#endif
   }
+}
+
+// One workgroup = DEC_PAIRS pairs of waves = DEC_CHANNELS channels: waves 0..3 code, wave 4 + p parses for wave p (the CU
+// deals a workgroup's waves out to its four SIMDs in turn, so the two land on the same SIMD; nothing but speed depends
+// on it).  LDS: division magics (64 KiB) | per pair: stream ring, DMA rows, decoded-word ring, two published rows,
+// sample ring -- 159 KiB for the 32-bit variants.
+// NARROW: valuesize < 32.  W64: valuesize 33..64 -- a.x is int64 [T][ld]; the parser is SegParser64 (no short-codeword
+// passes), samples take two LDS slots.  F32OUT: the decoded value, read back as valuesize bits sign extended
+// (normalize.c:36-37), leaves as (float)n / factor (:38, IEEE division) -- float32 rows [T][ld] also for W64, no
+// integer intermediate in HBM.
+template <bool ADAPTIVE, bool NARROW = false, bool W64 = false, bool F32OUT = false>
+__global__ void __launch_bounds__(DEC_BLOCK) dega_decode_kernel(const DecodeArgs a)
+{
+  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
+  // decoded samples a lane may run ahead of the slowest lane of its wave before it has to wait for the row writer
+  constexpr uint32_t SRING = W64 ? DEC_SRING : 64;
+  constexpr uint32_t PER_PAIR = (DEC_IRING + 4 + DEC_BRING + 2 + (W64 ? 2 : 1) * (SRING + 1)) * 64; // + a spare sample slot
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + DEC_PAIRS * PER_PAIR];
+  static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
+  uint32_t *const tab = lds;
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = wave_uniform(threadIdx.x >> 6);
+  const uint32_t pair = wave % DEC_PAIRS;
+  const bool parses = wave >= DEC_PAIRS;
+  uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
+  if (!parses) // nothing handed over, nothing taken
+  {
+    pair_lds[(DEC_IRING + 4 + DEC_BRING) * 64 + lane] = 0;
+    pair_lds[(DEC_IRING + 4 + DEC_BRING + 1) * 64 + lane] = 0;
+  }
+  load_div_table<ADAPTIVE>(tab, a.div_magic); // ends with the workgroup's only barrier
+
+  const size_t c_wave0 = (size_t)blockIdx.x * DEC_CHANNELS + pair * 64u;
+  const size_t c = c_wave0 + lane;
+  const bool live = c < a.C;
+  if (parses)
+    decode_parsing_wave<NARROW, W64, F32OUT, SRING>(a, pair_lds, lane, c, live, c_wave0);
+  else
+    decode_coding_wave<ADAPTIVE>(a, tab, pair_lds, lane, c, live);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -704,34 +704,18 @@ namespace dg
 
 constexpr int32_t ERR_LIBRARY_CALL = -11;
 
-// A lane's view of its compressed stream: 32-bit big-endian words staged in the lane's column of an LDS ring
-// (slot-major, ring[(k % IRING) * 64 + lane]); bits at or beyond `nbits` read as zero (the reference tolerates up to 14
-// such phantom bits after the end of the stream, bac.c:171-186,192).
+// A lane's view of its compressed stream: 32-bit words staged in the lane's column of an LDS ring (slot-major,
+// ring[(k % IRING) * 64 + lane]).  The words are "cooked" when they are staged (StreamTail::cook): host byte order, the
+// bits at or beyond the stream's exact length cleared, and every word beyond the last one reads as zero -- the reference
+// tolerates up to 14 such phantom bits after the end of the stream (bac.c:171-186,192).
 template <uint32_t IRING>
 struct StreamWindow
 {
   const uint32_t *ring_col; // &ring[lane]
-  uint64_t nbits;           // exact stream length
-
-  DG_DEV uint32_t raw(uint32_t k) const // word k as it sits in the ring: big-endian, not yet cut at the stream's end
-  {
-    return ring_col[(k % IRING) * 64u];
-  }
-
-  DG_DEV uint32_t cook(uint32_t raw_word, uint32_t k) const
-  {
-    const uint64_t first = (uint64_t)k * 32u;
-    uint32_t w = bswap32(raw_word);
-    if (first >= nbits)
-      w = 0;
-    else if (nbits - first < 32u)
-      w &= ~(0xFFFFFFFFu >> (uint32_t)(nbits - first));
-    return w;
-  }
 
   DG_DEV uint32_t word(uint32_t k) const
   {
-    return cook(raw(k), k);
+    return ring_col[(k % IRING) * 64u];
   }
 
   // 32 stream bits starting at bit position pos (words k = pos/32 and k+1 must be staged)
@@ -740,6 +724,28 @@ struct StreamWindow
     const uint32_t k = (uint32_t)(pos >> 5), o = (uint32_t)pos & 31u;
     const uint32_t w0 = word(k), w1 = word(k + 1u);
     return o ? (w0 << o) | (w1 >> (32u - o)) : w0;
+  }
+};
+
+// Where a lane's stream ends, in the form the staging step needs: word k of the slab is part of the stream iff
+// k < words; the last of them keeps only its leading bits.
+struct StreamTail
+{
+  uint32_t words;     // min(ceil(nbits / 32), slab words)
+  uint32_t last_mask; // of word words - 1
+
+  DG_DEV void init(uint64_t nbits, uint32_t cap_words)
+  {
+    const uint64_t all = (nbits + 31u) / 32u;
+    const uint32_t part = (uint32_t)nbits & 31u;
+    words = all < cap_words ? (uint32_t)all : cap_words;
+    last_mask = (all <= cap_words && part != 0u) ? ~(0xFFFFFFFFu >> part) : 0xFFFFFFFFu;
+  }
+
+  DG_DEV uint32_t cook(uint32_t raw_word, uint32_t k) const // raw_word: the slab's word k as loaded (big-endian)
+  {
+    const uint32_t w = bswap32(raw_word) & (k + 1u == words ? last_mask : 0xFFFFFFFFu);
+    return k < words ? w : 0u;
   }
 };
 
@@ -876,14 +882,14 @@ struct BacDecoder
       Mg[i] = mg[i];
   }
 
-  // pre[0..3]: the ring's words bp/32 .. bp/32 + 3 as read (StreamWindow::raw) -- the kernel reads them a step early
-  template <bool GENERAL, uint32_t IRING>
-  DG_DEV bool decode_word(const StreamWindow<IRING> &in, const uint32_t *magic, uint32_t (&Mg)[32], const uint32_t (&pre)[4], uint32_t &bits_out)
+  // pre[0..3]: the stream's words bp/32 .. bp/32 + 3 (StreamWindow::word) -- the kernel reads them ahead of its ballots
+  template <bool GENERAL>
+  DG_DEV bool decode_word(const uint32_t *magic, uint32_t (&Mg)[32], const uint32_t (&pre)[4], uint32_t &bits_out)
   {
     const uint32_t sh_fast = div_shift(tot);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
-    const uint32_t w0 = in.cook(pre[0], k0), w1 = in.cook(pre[1], k0 + 1u), w2 = in.cook(pre[2], k0 + 2u), w3 = in.cook(pre[3], k0 + 3u);
+    const uint32_t w0 = pre[0], w1 = pre[1], w2 = pre[2], w3 = pre[3];
     const uint32_t tot_word = tot;
     uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2:w3
     uint32_t off_group = off;
@@ -1014,6 +1020,13 @@ struct SegParser
       win |= (uint64_t)bits << (64u - n) >> cnt;
       cnt += n;
     }
+  }
+
+  // n <= 32 bits LEFT aligned in `word`, the rest of it zero; cnt <= 32.  Branch free (n = 0 with word = 0 changes nothing).
+  DG_DEV void push_word(uint32_t word, uint32_t n)
+  {
+    win |= ((uint64_t)word << 32) >> (cnt & 63u);
+    cnt += n;
   }
 
   DG_DEV void drop(uint32_t n) // n <= cnt, n <= 63... (n == 64 only when cnt == 64)
@@ -1157,6 +1170,12 @@ struct SegParser64
       win |= (uint64_t)bits << (64u - n) >> cnt;
       cnt += n;
     }
+  }
+
+  DG_DEV void push_word(uint32_t word, uint32_t n) // as SegParser::push_word
+  {
+    win |= ((uint64_t)word << 32) >> (cnt & 63u);
+    cnt += n;
   }
 
   DG_DEV void drop(uint32_t n)

@@ -53,18 +53,18 @@ extern "C" __attribute__((visibility("default"))) int sim_decode_var_vs(const ui
 {
   static const std::vector<uint32_t> tab = make_table();
   DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), counts, (uint32_t)valuesize};
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  const dim3 grid((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS));
   if (valuesize < 32)
   {
     if (adaptive)
-      sim::launch(dega_decode_kernel<true, true>, grid, dim3(BLOCK), a);
+      sim::launch(dega_decode_kernel<true, true>, grid, dim3(DEC_BLOCK), a);
     else
-      sim::launch(dega_decode_kernel<false, true>, grid, dim3(BLOCK), a);
+      sim::launch(dega_decode_kernel<false, true>, grid, dim3(DEC_BLOCK), a);
   }
   else if (adaptive)
-    sim::launch(dega_decode_kernel<true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_decode_kernel<true>, grid, dim3(DEC_BLOCK), a);
   else
-    sim::launch(dega_decode_kernel<false>, grid, dim3(BLOCK), a);
+    sim::launch(dega_decode_kernel<false>, grid, dim3(DEC_BLOCK), a);
   return 0;
 }
 
@@ -271,12 +271,12 @@ extern "C" __attribute__((visibility("default"))) int sim_encode_wide(const int3
 extern "C" __attribute__((visibility("default"))) int sim_decode_wide(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
-  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr, 32u};
-  const dim3 grid((unsigned)((C + 511) / 512));
+  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr, 32u}; // (one decode shape since the paired waves)
+  const dim3 grid((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS));
   if (adaptive)
-    sim::launch(dega_decode_kernel<true, false, 8>, grid, dim3(512), a);
+    sim::launch(dega_decode_kernel<true>, grid, dim3(DEC_BLOCK), a);
   else
-    sim::launch(dega_decode_kernel<false, false, 8>, grid, dim3(512), a);
+    sim::launch(dega_decode_kernel<false>, grid, dim3(DEC_BLOCK), a);
   return 0;
 }
 
@@ -297,11 +297,11 @@ extern "C" __attribute__((visibility("default"))) int sim_decode64(const uint8_t
 {
   static const std::vector<uint32_t> tab = make_table();
   DecodeArgs a{in, cap, in_bits, C, T, ld, reinterpret_cast<int32_t *>(x), err, tab.data(), counts, (uint32_t)valuesize};
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  const dim3 grid((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS));
   if (adaptive)
-    sim::launch(dega_decode_kernel<true, false, 4, true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_decode_kernel<true, false, true>, grid, dim3(DEC_BLOCK), a);
   else
-    sim::launch(dega_decode_kernel<false, false, 4, true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_decode_kernel<false, false, true>, grid, dim3(DEC_BLOCK), a);
   return 0;
 }
 
