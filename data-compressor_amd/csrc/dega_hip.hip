@@ -278,13 +278,10 @@ static int check_job_shape(dega_hip_ctx *ctx, const Shape &j, size_t cap)
 }
 
 template <bool AD, bool NARROW, bool F32>
-static void encode_launch(bool eight_waves, size_t C, hipStream_t s, const EncodeArgs &a)
+static void encode_launch(size_t C, hipStream_t s, const EncodeArgs &a)
 {
-  if (eight_waves) // more than one wave per SIMD of work: 8-wave workgroups with smaller rings, two waves per SIMD
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 8, 4, 16, 24, false, F32>), dim3((unsigned)((C + 511) / 512)), dim3(512), 0, s, a);
-  else
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, WAVES, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + BLOCK - 1) / BLOCK)),
-                       dim3(BLOCK), 0, s, a);
+  hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
+                     dim3(ENC_BLOCK), 0, s, a);
 }
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
@@ -315,23 +312,23 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
   a.lo = -(float)((uint64_t)1 << (vs - 1));
   a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
-  const bool eight = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
+  (void)batch_C; // one workgroup shape for every batch size: pairs of waves, two per SIMD (dega_kernels.hpp)
   {
     LaunchTimer lt(ctx, 0, s);
-    if (vs > 32) // 64-bit values: one shape
+    if (vs > 32) // 64-bit values
     {
-      const dim3 grid((unsigned)((j.C + BLOCK - 1) / BLOCK));
+      const dim3 grid((unsigned)((j.C + ENC_CHANNELS - 1) / ENC_CHANNELS));
       if (f32)
       {
         if (ad)
-          hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true, true>), grid, dim3(BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
         else
-          hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true, true>), grid, dim3(BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
       }
       else if (ad)
-        hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 4, 32, 32, true, false>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
       else
-        hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 4, 32, 32, true, false>), grid, dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
     }
     else
     {
@@ -339,14 +336,14 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
       const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
       switch (sel)
       {
-        case 0: encode_launch<false, false, false>(eight, j.C, s, a); break;
-        case 1: encode_launch<false, false, true>(eight, j.C, s, a); break;
-        case 2: encode_launch<false, true, false>(eight, j.C, s, a); break;
-        case 3: encode_launch<false, true, true>(eight, j.C, s, a); break;
-        case 4: encode_launch<true, false, false>(eight, j.C, s, a); break;
-        case 5: encode_launch<true, false, true>(eight, j.C, s, a); break;
-        case 6: encode_launch<true, true, false>(eight, j.C, s, a); break;
-        default: encode_launch<true, true, true>(eight, j.C, s, a); break;
+        case 0: encode_launch<false, false, false>(j.C, s, a); break;
+        case 1: encode_launch<false, false, true>(j.C, s, a); break;
+        case 2: encode_launch<false, true, false>(j.C, s, a); break;
+        case 3: encode_launch<false, true, true>(j.C, s, a); break;
+        case 4: encode_launch<true, false, false>(j.C, s, a); break;
+        case 5: encode_launch<true, false, true>(j.C, s, a); break;
+        case 6: encode_launch<true, true, false>(j.C, s, a); break;
+        default: encode_launch<true, true, true>(j.C, s, a); break;
       }
     }
   }

@@ -196,8 +196,10 @@ DG_DEV void peer_store(uint32_t *lds_word, uint32_t v)
 #if defined(DEGA_SIM)
   __atomic_store_n(lds_word, v, __ATOMIC_RELEASE);
 #else
+  // (a volatile access through a generic pointer would become a FLAT instruction -- the slow path to LDS, tracked by
+  // vmcnt together with the wave's global traffic: name the address space)
   DG_COMPILER_BARRIER();
-  *reinterpret_cast<volatile uint32_t *>(lds_word) = v;
+  *(volatile __attribute__((address_space(3))) uint32_t *)lds_word = v;
   DG_COMPILER_BARRIER();
 #endif
 }
@@ -207,7 +209,7 @@ DG_DEV uint32_t peer_load(const uint32_t *lds_word)
   return __atomic_load_n(lds_word, __ATOMIC_ACQUIRE);
 #else
   DG_COMPILER_BARRIER();
-  const uint32_t v = *reinterpret_cast<const volatile uint32_t *>(lds_word);
+  const uint32_t v = *(const volatile __attribute__((address_space(3))) uint32_t *)lds_word;
   DG_COMPILER_BARRIER();
   return v;
 #endif

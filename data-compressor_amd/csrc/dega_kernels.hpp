@@ -96,45 +96,56 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
   __syncthreads();
 }
 
-// NW waves per workgroup, ROWS rows per fill batch, RING / ORING words of seg-bit / output ring per lane.  Two shapes are
-// instantiated: <4, 8, 32, 32> -- one wave per SIMD, for batches of up to 64 Ki channels (all the waves there are) -- and
-// <8, 4, 16, 24> for larger batches: eight waves share the table, the smaller rings keep the workgroup within the CU's
-// LDS (154 KiB), and the second wave of each SIMD fills the issue slots the first leaves empty while it waits.
+// One workgroup = ENC_PAIRS pairs of waves = ENC_CHANNELS channels.  Of each pair (wave p and wave p + 4: the CU deals a
+// workgroup's waves out to its four SIMDs in turn, so the two share a SIMD) the first FILLS -- rows in, seg bits into the
+// lane's column of an LDS ring -- and the second CODES: ring words through the arithmetic coder, coded words to the slab.
+// A channel's coder is serial and instruction bound, and 64 Ki channels are only one coding wave per SIMD: with the row
+// traffic, the row lockstep and their waits in a wave of their own, the coding wave does nothing but code, and whatever
+// it still waits for, the filling wave's instructions go into.  The two talk through one published word per lane and
+// direction (counters modulo 2^16, peer_store / peer_load); a wave with nothing to do sleeps.
+//   filler publishes: ring words written (mod 2^16) | bits of the final, partial word << 16 | all rows done << 24 |
+//                     a value was out of range << 25
+//   coder publishes:  ring words consumed (mod 2^16)
+// ROWS rows per fill batch, RING / ORING words of seg-bit / output ring per lane.
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
-// writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated as <.., 4, 4, 32, 32, true>.
+// writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated with ROWS = 4.
 // F32IN: the rows are float32 readings; Normalize (normalize.c:16-24) runs on each value as it leaves LDS, in front of
 // the difference -- one launch, no int32 intermediate in HBM.  With W64 the rows stay one dword per lane (floats) and
 // the normalized value is 64 bits wide (valuesize 33..64, normalize.c:21-24 with io_int_t = int64).
-template <bool ADAPTIVE, bool NARROW = false, uint32_t NW = WAVES, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING,
-          bool W64 = false, bool F32IN = false>
-__global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a)
+#ifndef DG_ENC_FILL_SLEEP
+#define DG_ENC_FILL_SLEEP 2
+#endif
+#ifndef DG_ENC_CODE_SLEEP
+#define DG_ENC_CODE_SLEEP 1
+#endif
+#ifndef DG_ENC_CODE_PRIO
+#define DG_ENC_CODE_PRIO 3
+#endif
+#ifndef DG_DEC_PARSE_SLEEP
+#define DG_DEC_PARSE_SLEEP 2
+#endif
+#ifndef DG_DEC_CODE_SLEEP
+#define DG_DEC_CODE_SLEEP 1
+#endif
+#ifndef DG_DEC_CODE_PRIO
+#define DG_DEC_CODE_PRIO 0
+#endif
+constexpr uint32_t ENC_PAIRS = 4;
+constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
+constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
+constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25;
+
+// ---- the filling wave ------------------------------------------------------------------------------------------------
+template <bool NARROW, uint32_t ROWS, uint32_t RING, bool W64, bool F32IN>
+DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_t *rows_wave, uint32_t *pub_mine, const uint32_t *pub_peer, uint32_t lane,
+                                size_t c, bool live, size_t c_wave0)
 {
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
   constexpr uint32_t FILL_WORDS = (31 + (W64 ? 127 : 65) * ROWS) / 32; // most words a batch can add (worst-case codewords)
   constexpr bool ROWS64 = W64 && !F32IN; // rows of two dwords per lane
-  constexpr uint32_t LDS_ROWS = ROWS64 ? 2 * ROWS : ROWS;
-  static_assert(FILL_WORDS < RING && ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
+  static_assert(FILL_WORDS < RING, "ring too small");
   const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
-  // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
-  // access with a vmcnt(0) wait):  division magics (64 KiB) | seg-bit rings | coded-word rings | input rows
-  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  __shared__ uint32_t lds[TAB_WORDS + NW * (RING + ORING + LDS_ROWS) * 64];
-  uint32_t *const tab = lds;
-  uint32_t *const ring = tab + TAB_WORDS;              // seg bits waiting to be coded, per lane
-  uint32_t *const oring = ring + NW * RING * 64;  // coded words waiting to be stored, per lane
-  uint32_t *const xrows = oring + NW * ORING * 64; // the next input rows, per lane
 
-  load_div_table<ADAPTIVE>(tab, a.div_magic);
-
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  const size_t c = (size_t)blockIdx.x * (NW * 64u) + threadIdx.x;
-  const bool live = c < a.C;
-  uint32_t *const ring_col = &ring[wave * RING * 64 + lane];
-
-  BacEncoder<ADAPTIVE, ORING> enc;
-  enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u,
-           &oring[wave * ORING * 64 + lane]);
   BitQueue q;
   q.init();
   uint32_t last = 0; // diff.c:11
@@ -142,12 +153,8 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   int32_t lane_err = OK;
 
   // Input rows travel HBM -> LDS directly (LDS-DMA, `global_load_lds_dword`: one 256-byte row segment per wave
-  // instruction, no VGPR destination) and are read from LDS by the next fill.  All vector-memory traffic of an
-  // iteration -- the row DMA and the drain's stores -- is issued at the END of the iteration; the single vmcnt wait
-  // sits right after the NEXT iteration's code step, ~6000 cycles later, when everything has long retired.  (vmcnt
-  // retires in order: with register loads hipcc placed vmcnt(0) waits right behind the drain's stores -- 26 % of all
-  // cycles -- and copied freshly loaded registers at the loop's back edge.)
-  uint32_t *const rows_wave = &xrows[wave * LDS_ROWS * 64]; // wave uniform
+  // instruction, no VGPR destination) and are read from LDS by the next fill; the next batch is requested right after a
+  // fill and has the coder's next two or three steps to arrive.
   const uint32_t *const rows_col = rows_wave + lane;
   size_t t = 0; // rows consumed by fills, wave uniform; after the wait LDS holds rows [t, t + ROWS)
   const size_t t_last = a.T > 0 ? a.T - 1 : 0;
@@ -156,7 +163,6 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
 
   // When the wave's 64 channels all exist and rows are 16-byte aligned, one LDS-DMA instruction fetches FOUR rows:
   // lanes 16r .. 16r+15 read row r's 256 bytes as 16-byte pieces, which land as row r of the [row][64] LDS image.
-  const size_t c_wave0 = (size_t)blockIdx.x * (NW * 64u) + wave * 64u;
   const bool rows_x4 = !ROWS64 && (ROWS % 4 == 0) && c_wave0 + 64 <= a.C && (a.ld % 4 == 0) && (((size_t)a.x) % 16 == 0);
   auto issue_rows = [&](size_t t0) // rows [t0, t0 + ROWS), clamped to the last row
   {
@@ -178,12 +184,12 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
     }
     if (rows_x4)
     {
-      const uint32_t r = lane >> 4, q = lane & 15u;
+      const uint32_t r = lane >> 4, q4 = lane & 15u;
 #pragma unroll
       for (uint32_t j = 0; j < ROWS / 4; j++)
       {
         const size_t row = t0 + 4 * j + r < a.T ? t0 + 4 * j + r : t_last;
-        dma_x4_to_lds(a.x + row * a.ld + c_wave0 + q * 4u, rows_wave + j * 256u, lane);
+        dma_x4_to_lds(a.x + row * a.ld + c_wave0 + q4 * 4u, rows_wave + j * 256u, lane);
       }
       return;
     }
@@ -200,193 +206,216 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
   if (a.T > 0)
     issue_rows(0);
 
+  while (t < a.T)
+  {
+    // ---- the same ROWS rows for every lane, as soon as every lane's ring has room for what they may add ---------------
+    const uint32_t taken = peer_load(pub_peer);
+    const bool room = ((q.wr - taken) & 0xFFFFu) + FILL_WORDS <= RING;
+    if (!wave_all(room))
+    {
+      wave_sleep<DG_ENC_FILL_SLEEP>();
+      continue;
+    }
+    wait_vector_memory();
+    const size_t left = a.T - t;
+    if constexpr (W64)
+    {
+      const uint64_t vmask64 = a.valuesize >= 64u ? ~0ull : (1ull << a.valuesize) - 1ull;
+      if (live)
+      {
+#pragma unroll
+        for (uint32_t i = 0; i < ROWS; i++)
+          if (i < left)
+          {
+            uint64_t u;
+            if constexpr (F32IN)
+            {
+              if (!normalize_value64(__uint_as_float(rows_col[i * 64u]), a.factor, u, a.lo, a.hi, vmask64) && lane_err == OK)
+                lane_err = ERR_INVALID_VALUE; // normalize.c:21-22
+            }
+            else
+              u = (((uint64_t)rows_col[(2u * i + 1u) * 64u] << 32) | rows_col[(2u * i) * 64u]) & vmask64;
+            const SegWord64 sw = diff_seg64(u, last64, a.valuesize);
+            if (!sw.ok && lane_err == OK)
+              lane_err = ERR_INVALID_VALUE;
+            q.put_codeword64<RING>(sw, ring_col);
+          }
+      }
+    }
+    else
+    {
+      uint32_t xr[ROWS];
+#pragma unroll
+      for (uint32_t i = 0; i < ROWS; i++)
+        xr[i] = rows_col[i * 64u];
+#pragma unroll
+      for (uint32_t i = 0; i < ROWS; i++)
+        DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
+      if constexpr (F32IN)
+      {
+        // Normalize (normalize.c:16-24) on the way in; rows past the end of the channel repeat the last row, whose
+        // verdict is the same, so the whole batch can be checked
+        bool all_in_range = true;
+#pragma unroll
+        for (uint32_t i = 0; i < ROWS; i++)
+        {
+          int32_t n;
+          all_in_range = normalize_value(__uint_as_float(xr[i]), a.factor, n, a.lo, a.hi, vmask) && all_in_range;
+          xr[i] = (uint32_t)n;
+        }
+        if (!all_in_range && lane_err == OK)
+          lane_err = ERR_INVALID_VALUE;
+      }
+      else
+      {
+        if (a.big_endian) // wave uniform
+        {
+#pragma unroll
+          for (uint32_t i = 0; i < ROWS; i++)
+            xr[i] = bswap32(xr[i]);
+        }
+        if (NARROW)
+        {
+#pragma unroll
+          for (uint32_t i = 0; i < ROWS; i++)
+            xr[i] &= vmask;
+        }
+      }
+      // Pass 1, no side effects: the codeword values of the whole batch, assuming the steady state -- every sample
+      // below 2^31 (then every difference fits, diff.c:17-18) and every codeword short (|delta| < 2^15): one OR over
+      // the batch answers both
+      uint32_t w[ROWS];
+      uint32_t last_try = last, seen = last, wseen = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < ROWS; i++)
+      {
+        w[i] = diff_seg_steady(xr[i], last_try);
+        seen |= xr[i];
+        wseen |= w[i];
+      }
+      const bool plain = NARROW ? false : ((seen >> 31) | (wseen >> 16)) == 0u; // narrow values: range check per sample
+      if (left >= ROWS && !wave_any(!plain && live))
+      {
+        // the steady state: a full batch of short codewords, straight-line appends
+        if (live)
+        {
+          last = last_try;
+#pragma unroll
+          for (uint32_t i = 0; i < ROWS; i++)
+            q.put_short<RING>(w[i], ring_col);
+        }
+      }
+      else if (live)
+      {
+        // first samples of a channel, jumps, narrow value sizes, the last partial batch: the general three-piece
+        // writer, row by row
+#pragma unroll
+        for (uint32_t i = 0; i < ROWS; i++)
+        {
+          if (i < left)
+          {
+            const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
+            if (!sw.ok && lane_err == OK)
+              lane_err = ERR_INVALID_VALUE;
+            q.put_codeword<RING>(sw, ring_col);
+          }
+        }
+      }
+    }
+    t += left < ROWS ? left : ROWS;
+    if (t < a.T)
+      issue_rows(t); // in flight while the coder works through this batch
+    peer_store(pub_mine, q.wr & 0xFFFFu);
+  }
+  // the last, partial word of the seg stream goes into the next ring slot, left aligned (the slot is free: a batch's
+  // worst case counts it)
+  ring_col[(q.wr % RING) * 64u] = q.cnt != 0u ? (uint32_t)(q.acc << (32u - q.cnt)) : 0u;
+  peer_store(pub_mine, (q.wr & 0xFFFFu) | (q.cnt << 16) | ENC_PUB_DONE | (lane_err != OK ? ENC_PUB_BAD : 0u));
+}
+
+// ---- the coding wave -------------------------------------------------------------------------------------------------
+template <bool ADAPTIVE, uint32_t RING, uint32_t ORING>
+DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const uint32_t *ring_col, uint32_t *oring_col, uint32_t *pub_mine,
+                               const uint32_t *pub_peer, uint32_t lane, size_t c, bool live)
+{
+  BacEncoder<ADAPTIVE, ORING> enc;
+  enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u, oring_col);
+  uint32_t rd = 0; // ring words coded so far
+  uint32_t peer;
+  wave_priority<DG_ENC_CODE_PRIO>();
+
   DG_STAMP_DECL;
   for (;;)
   {
     DG_STAMP(7);
-    // ---- phase C: one queued word (32 symbols) for every lane that has one ---------------------------------------
-    const bool has = q.wr != q.rd;
-    // What a code step reads from LDS first -- the queued word and the first quarter of its division magics -- is asked
-    // for here, ahead of the ballots that choose the word path; nothing LDS is carried around the loop (a wait at the
-    // back edge would be a wait for the whole queue).
-    const uint32_t word = ring_col[(q.rd % RING) * 64u];
+    // ---- one queued word (32 symbols) for every lane that has one ------------------------------------------------------
+    // What a code step reads from LDS first -- the filler's count, the queued word and the first quarter of its division
+    // magics -- is asked for here, ahead of the ballots that choose the word path; nothing LDS is carried around the loop
+    // (a wait at the back edge would be a wait for the whole queue).
+    peer = peer_load(pub_peer);
+    const uint32_t word = ring_col[(rd % RING) * 64u];
     uint32_t Mg[32];
     enc.fetch_magics_first(tab, Mg);
+    const bool has = ((peer - rd) & 0xFFFFu) != 0u;
     const bool any_has = wave_any(has);
     DG_STAMP(2);
-    if (any_has)
+    if (!any_has)
     {
-      // Which word path?  Every lane knows the class of its next word and for how many words that class still holds
-      // (BacEncoder::classify: looked at again only when the count has run out); the wave takes the most expensive
-      // class among its lanes.  In the steady state this is one ballot.
-      if (wave_any(has && enc.safe == 0u))
-      {
-        if (has && enc.safe == 0u)
-          enc.classify();
-      }
-      const uint32_t cls = has ? enc.cls : CLS_FAST8;
-      uint32_t record = 0, groups = 4; // a carry past the held-back word, recorded by the word path (see settle_ripples)
-      if (!wave_any(cls != CLS_FAST8))
-      {
-        if (has)
-          record = enc.template encode_word<false, 8>(word, tab, Mg);
-        DG_STAMP(3);
-      }
-      else
-      {
-        const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
-        groups = 8;
-        if (has)
-        {
-          if (any_bits)
-          {
-#pragma unroll 1
-            for (uint32_t i = 0; i < 32; i++)
-              enc.encode_bit((word >> (31u - i)) & 1u, tab);
-          }
-          else if (any_general)
-          {
-            if constexpr (ADAPTIVE)
-              record = enc.template encode_word<true, 4>(word, tab, Mg);
-          }
-          else
-            record = enc.template encode_word<false, 4>(word, tab, Mg);
-        }
-        DG_STAMP(4);
-      }
-      if (wave_any(record != 0u)) // once in 2^32 hand-overs of random data
-      {
-        if (record != 0u)
-          enc.settle_word(record, groups);
-      }
+      if (wave_all((peer & ENC_PUB_DONE) != 0u))
+        break; // all rows consumed and every queue drained
+      wave_sleep<DG_ENC_CODE_SLEEP>();
+      continue;
+    }
+    // Which word path?  Every lane knows the class of its next word and for how many words that class still holds
+    // (BacEncoder::classify: looked at again only when the count has run out); the wave takes the most expensive
+    // class among its lanes.  In the steady state this is one ballot.
+    if (wave_any(has && enc.safe == 0u))
+    {
+      if (has && enc.safe == 0u)
+        enc.classify();
+    }
+    const uint32_t cls = has ? enc.cls : CLS_FAST8;
+    uint32_t record = 0, groups = 4; // a carry past the held-back word, recorded by the word path (see settle_ripples)
+    if (!wave_any(cls != CLS_FAST8))
+    {
+      if (has)
+        record = enc.template encode_word<false, 8>(word, tab, Mg);
+      DG_STAMP(3);
+    }
+    else
+    {
+      const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
+      groups = 8;
       if (has)
       {
-        q.rd++;
-        enc.safe -= enc.safe != 0u ? 1u : 0u;
-      }
-    }
-    // ---- phase F: the same ROWS rows for every lane ----------------------------------------------------------
-    const bool room = (q.wr - q.rd) + FILL_WORDS <= RING;
-    const bool fill = t < a.T && wave_all(room);
-    DG_STAMP(0);
-    if (fill)
-    {
-      // The rows were requested right after the previous fill, one to three code steps ago; only a step that fills
-      // waits for them (a wait in every step would stop the steps in between for a DMA nobody needs yet).
-      wait_vector_memory();
-      DG_STAMP(5);
-      const size_t left = a.T - t;
-      if constexpr (W64)
-      {
-        const uint64_t vmask64 = a.valuesize >= 64u ? ~0ull : (1ull << a.valuesize) - 1ull;
-        if (live)
+        if (any_bits)
         {
-#pragma unroll
-          for (uint32_t i = 0; i < ROWS; i++)
-            if (i < left)
-            {
-              uint64_t u;
-              if constexpr (F32IN)
-              {
-                if (!normalize_value64(__uint_as_float(rows_col[i * 64u]), a.factor, u, a.lo, a.hi, vmask64) && lane_err == OK)
-                  lane_err = ERR_INVALID_VALUE; // normalize.c:21-22
-              }
-              else
-                u = (((uint64_t)rows_col[(2u * i + 1u) * 64u] << 32) | rows_col[(2u * i) * 64u]) & vmask64;
-              const SegWord64 sw = diff_seg64(u, last64, a.valuesize);
-              if (!sw.ok && lane_err == OK)
-                lane_err = ERR_INVALID_VALUE;
-              q.put_codeword64<RING>(sw, ring_col);
-            }
+#pragma unroll 1
+          for (uint32_t i = 0; i < 32; i++)
+            enc.encode_bit((word >> (31u - i)) & 1u, tab);
         }
-      }
-      else
-      {
-        uint32_t xr[ROWS];
-#pragma unroll
-        for (uint32_t i = 0; i < ROWS; i++)
-          xr[i] = rows_col[i * 64u];
-#pragma unroll
-        for (uint32_t i = 0; i < ROWS; i++)
-          DG_MATERIALISE(xr[i]); // one LDS wait here, none between the ring writes below
-        if constexpr (F32IN)
+        else if (any_general)
         {
-          // Normalize (normalize.c:16-24) on the way in; rows past the end of the channel repeat the last row, whose
-          // verdict is the same, so the whole batch can be checked
-          bool all_in_range = true;
-#pragma unroll
-          for (uint32_t i = 0; i < ROWS; i++)
-          {
-            int32_t n;
-            all_in_range = normalize_value(__uint_as_float(xr[i]), a.factor, n, a.lo, a.hi, vmask) && all_in_range;
-            xr[i] = (uint32_t)n;
-          }
-          if (!all_in_range && lane_err == OK)
-            lane_err = ERR_INVALID_VALUE;
+          if constexpr (ADAPTIVE)
+            record = enc.template encode_word<true, 4>(word, tab, Mg);
         }
         else
-        {
-          if (a.big_endian) // wave uniform
-          {
-#pragma unroll
-            for (uint32_t i = 0; i < ROWS; i++)
-              xr[i] = bswap32(xr[i]);
-          }
-          if (NARROW)
-          {
-#pragma unroll
-            for (uint32_t i = 0; i < ROWS; i++)
-              xr[i] &= vmask;
-          }
-        }
-        // Pass 1, no side effects: the codeword values of the whole batch, assuming the steady state -- every sample
-        // below 2^31 (then every difference fits, diff.c:17-18) and every codeword short (|delta| < 2^15): one OR over
-        // the batch answers both
-        uint32_t w[ROWS];
-        uint32_t last_try = last, seen = last, wseen = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < ROWS; i++)
-        {
-          w[i] = diff_seg_steady(xr[i], last_try);
-          seen |= xr[i];
-          wseen |= w[i];
-        }
-        const bool plain = NARROW ? false : ((seen >> 31) | (wseen >> 16)) == 0u; // narrow values: range check per sample
-        if (left >= ROWS && !wave_any(!plain && live))
-        {
-          // the steady state: a full batch of short codewords, straight-line appends
-          if (live)
-          {
-            last = last_try;
-#pragma unroll
-            for (uint32_t i = 0; i < ROWS; i++)
-              q.put_short<RING>(w[i], ring_col);
-          }
-        }
-        else if (live)
-        {
-          // first samples of a channel, jumps, narrow value sizes, the last partial batch: the general three-piece
-          // writer, row by row
-#pragma unroll
-          for (uint32_t i = 0; i < ROWS; i++)
-          {
-            if (i < left)
-            {
-              const SegWord sw = diff_seg<NARROW>(xr[i], last, vhalf);
-              if (!sw.ok && lane_err == OK)
-                lane_err = ERR_INVALID_VALUE;
-              q.put_codeword<RING>(sw, ring_col);
-            }
-          }
-        }
+          record = enc.template encode_word<false, 4>(word, tab, Mg);
       }
-      t += left < ROWS ? left : ROWS;
-      DG_STAMP(1);
-      if (t < a.T)
-        issue_rows(t); // in flight during the next code step
+      DG_STAMP(4);
     }
-    else if (!any_has)
-      break; // all rows consumed and every queue drained
+    if (wave_any(record != 0u)) // once in 2^32 hand-overs of random data
+    {
+      if (record != 0u)
+        enc.settle_word(record, groups);
+    }
+    if (has)
+    {
+      rd++;
+      enc.safe -= enc.safe != 0u ? 1u : 0u;
+    }
+    peer_store(pub_mine, rd & 0xFFFFu);
+    DG_STAMP(0);
     // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------------
     // As soon as some column could not take another word path's worth of output, every lane that holds a whole 64-byte
     // group stores it: four 16-byte stores to consecutive addresses, so a lane's stores fill whole 64-byte segments of
@@ -437,13 +466,13 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
 
   if (live)
   {
-    // the last, partial word of the seg stream, then EOF + flush (bac.c:163-164)
-    const uint32_t tail = q.cnt;
-    const uint32_t tword = tail ? (uint32_t)(q.acc << (32u - tail)) : 0u;
+    // the last, partial word of the seg stream (left aligned in the filler's next ring slot), then EOF + flush (bac.c:163-164)
+    const uint32_t tail = (peer >> 16) & 31u;
+    const uint32_t tword = ring_col[(rd % RING) * 64u];
     for (uint32_t i = 0; i < tail; i++)
       enc.encode_bit((tword >> (31u - i)) & 1u, tab);
     a.out_bits[c] = enc.finish(tab);
-    a.err[c] = lane_err != OK ? lane_err : enc.err;
+    a.err[c] = (peer & ENC_PUB_BAD) != 0u ? ERR_INVALID_VALUE : enc.err;
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
     if (lane < 8)
       a.out_bits[c] = stamp_sum[lane];
@@ -451,6 +480,48 @@ __global__ void __launch_bounds__(NW * 64) dega_encode_kernel(const EncodeArgs a
       a.out_bits[c] = stamp_cnt[lane - 8];
 #endif
   }
+}
+
+template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING, bool W64 = false, bool F32IN = false>
+__global__ void __launch_bounds__(ENC_BLOCK) dega_encode_kernel(const EncodeArgs a)
+{
+  constexpr uint32_t LDS_ROWS = (W64 && !F32IN) ? 2 * ROWS : ROWS;
+  static_assert(ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
+  // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
+  // access with a vmcnt(0) wait):  division magics (64 KiB) | per pair: seg-bit ring, coded-word ring, input rows, the
+  // two published rows
+  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
+  constexpr uint32_t PER_PAIR = (RING + ORING + LDS_ROWS + 2) * 64;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + ENC_PAIRS * PER_PAIR];
+  static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
+  uint32_t *const tab = lds;
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = wave_uniform(threadIdx.x >> 6);
+  const uint32_t pair = wave % ENC_PAIRS;
+  const bool codes = wave >= ENC_PAIRS;
+  uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
+  uint32_t *const ring_col = pair_lds + lane;                         // seg bits waiting to be coded
+  uint32_t *const oring_col = pair_lds + RING * 64 + lane;            // coded words waiting to be stored
+  uint32_t *const rows_wave = pair_lds + (RING + ORING) * 64;         // the next input rows (wave uniform)
+  uint32_t *const pub_filler = pair_lds + (RING + ORING + LDS_ROWS) * 64 + lane;
+  uint32_t *const pub_coder = pub_filler + 64;
+  if (!codes) // nothing written, nothing consumed
+  {
+    *pub_filler = 0;
+    *pub_coder = 0;
+  }
+  load_div_table<ADAPTIVE>(tab, a.div_magic); // ends with the workgroup's only barrier
+
+  const size_t c_wave0 = (size_t)blockIdx.x * ENC_CHANNELS + pair * 64u;
+  const size_t c = c_wave0 + lane;
+  const bool live = c < a.C;
+  if (!wave_any(live))
+    return; // a pair past the last channel
+  if (codes)
+    encode_coding_wave<ADAPTIVE, RING, ORING>(a, tab, ring_col, oring_col, pub_coder, pub_filler, lane, c, live);
+  else
+    encode_filling_wave<NARROW, ROWS, RING, W64, F32IN>(a, ring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
 }
 
 // =====================================================================================================================
@@ -538,6 +609,7 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
   uint32_t pub_flags = 0;
   if (!wave_any(live))
     return; // a wave past the last channel
+  wave_priority<DG_DEC_CODE_PRIO>();
 
   auto request_refill = [&]() // 4 more words for every lane that has ring room for them
   {
@@ -652,7 +724,7 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
       peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u));
       if (wave_all(bac_done))
         break;
-      wave_sleep<1>(); // waiting for the partner (ring full) or for stream words
+      wave_sleep<DG_DEC_CODE_SLEEP>(); // waiting for the partner (ring full) or for stream words
     }
     // ---- the DMA issued at the end of the previous step has landed: cook the words into the lane's own ring slots ----
     if (wave_any(requested))
@@ -754,7 +826,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     peer_store(pub_mine, (rd & 0xFFFFu) | (lane_final ? DEC_PUB_FINAL : 0u));
     if (!wave_any(got || (final_in && !lane_final)) && !carry_over)
     {
-      wave_sleep<2>();
+      wave_sleep<DG_DEC_PARSE_SLEEP>();
       continue;
     }
     if (final_in && (peer & DEC_PUB_BAD) != 0u && lane_err == OK)

@@ -29,18 +29,18 @@ extern "C" __attribute__((visibility("default"))) int sim_encode_vs(const int32_
 {
   static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), (uint32_t)valuesize};
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS));
   if (valuesize < 32)
   {
     if (adaptive)
-      sim::launch(dega_encode_kernel<true, true>, grid, dim3(BLOCK), a);
+      sim::launch(dega_encode_kernel<true, true>, grid, dim3(ENC_BLOCK), a);
     else
-      sim::launch(dega_encode_kernel<false, true>, grid, dim3(BLOCK), a);
+      sim::launch(dega_encode_kernel<false, true>, grid, dim3(ENC_BLOCK), a);
   }
   else if (adaptive)
-    sim::launch(dega_encode_kernel<true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_encode_kernel<true>, grid, dim3(ENC_BLOCK), a);
   else
-    sim::launch(dega_encode_kernel<false>, grid, dim3(BLOCK), a);
+    sim::launch(dega_encode_kernel<false>, grid, dim3(ENC_BLOCK), a);
   return 0;
 }
 
@@ -260,11 +260,11 @@ extern "C" __attribute__((visibility("default"))) int sim_encode_wide(const int3
 {
   static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), 32u};
-  const dim3 grid((unsigned)((C + 511) / 512));
+  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)); // (the small-ring shape: 4 rows per batch, 16 / 24 ring words)
   if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 8, 4, 16, 24>, grid, dim3(512), a);
+    sim::launch(dega_encode_kernel<true, false, 4, 16, 24>, grid, dim3(ENC_BLOCK), a);
   else
-    sim::launch(dega_encode_kernel<false, false, 8, 4, 16, 24>, grid, dim3(512), a);
+    sim::launch(dega_encode_kernel<false, false, 4, 16, 24>, grid, dim3(ENC_BLOCK), a);
   return 0;
 }
 
@@ -285,11 +285,11 @@ extern "C" __attribute__((visibility("default"))) int sim_encode64(const int64_t
 {
   static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{reinterpret_cast<const int32_t *>(x), C, T, ld, out, cap, bits, err, tab.data(), (uint32_t)valuesize};
-  const dim3 grid((unsigned)((C + BLOCK - 1) / BLOCK));
+  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS));
   if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 4, 4, 32, 32, true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_encode_kernel<true, false, 4, 32, 32, true>, grid, dim3(ENC_BLOCK), a);
   else
-    sim::launch(dega_encode_kernel<false, false, 4, 4, 32, 32, true>, grid, dim3(BLOCK), a);
+    sim::launch(dega_encode_kernel<false, false, 4, 32, 32, true>, grid, dim3(ENC_BLOCK), a);
   return 0;
 }
 
