@@ -369,12 +369,13 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     // Which word path?  Every lane knows the class of its next word and for how many words that class still holds
     // (BacEncoder::classify: looked at again only when the count has run out); the wave takes the most expensive
     // class among its lanes.  In the steady state this is one ballot.
-    if (wave_any(has && enc.safe == 0u))
+    if (wave_any(has && enc.safe == 0u && enc.part_lo == 0u))
     {
-      if (has && enc.safe == 0u)
+      if (has && enc.safe == 0u && enc.part_lo == 0u)
         enc.classify();
     }
-    const uint32_t cls = has ? enc.cls : CLS_FAST8;
+    uint32_t cls = has ? enc.cls : CLS_FAST8;
+    bool act = has; // lanes that code (a part of) a word in this step
     uint32_t record = 0, groups = 4; // a carry past the held-back word, recorded by the word path (see settle_ripples)
     if (!wave_any(cls != CLS_FAST8))
     {
@@ -384,34 +385,65 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     }
     else
     {
-      const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
-      groups = 8;
-      if (has)
+      // A lane in the middle of a halving word (CLS_SPLIT, second part) needs the masked fast path: lanes that need a
+      // slower one sit this step out.  A halving word not yet begun goes whole through the general path when the
+      // wave takes that one anyway.
+      if (wave_any(has && enc.part_lo != 0u))
+        act = has && cls <= CLS_SPLIT;
+      else if (wave_any(cls > CLS_SPLIT))
       {
-        if (any_bits)
+        if (cls == CLS_SPLIT)
         {
-#pragma unroll 1
-          for (uint32_t i = 0; i < 32; i++)
-            enc.encode_bit((word >> (31u - i)) & 1u, tab);
+          cls = CLS_GENERAL;
+          enc.whole_word();
         }
-        else if (any_general)
-        {
-          if constexpr (ADAPTIVE)
-            record = enc.template encode_word<true, 4>(word, tab, Mg);
-        }
-        else
-          record = enc.template encode_word<false, 4>(word, tab, Mg);
       }
-      DG_STAMP(4);
+      if (!wave_any(act && cls > CLS_SPLIT))
+      {
+        if constexpr (ADAPTIVE)
+        {
+          if (act)
+            record = enc.template encode_word<false, 8, true>(word, tab, Mg);
+        }
+        DG_STAMP(4);
+      }
+      else
+      {
+        const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
+        groups = 8;
+        if (has)
+        {
+          if (any_bits)
+          {
+#pragma unroll 1
+            for (uint32_t i = 0; i < 32; i++)
+              enc.encode_bit((word >> (31u - i)) & 1u, tab);
+          }
+          else if (any_general)
+          {
+            if constexpr (ADAPTIVE)
+              record = enc.template encode_word<true, 4>(word, tab, Mg);
+          }
+          else
+            record = enc.template encode_word<false, 4>(word, tab, Mg);
+        }
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+        if (any_bits)
+          DG_STAMP(5);
+        else
+          DG_STAMP(1);
+#endif
+      }
     }
     if (wave_any(record != 0u)) // once in 2^32 hand-overs of random data
     {
       if (record != 0u)
         enc.settle_word(record, groups);
     }
-    if (has)
+    if (act)
     {
-      rd++;
+      const bool whole = enc.cls != CLS_SPLIT || cls != CLS_SPLIT || enc.after_part(word);
+      rd += whole ? 1u : 0u;
       enc.safe -= enc.safe != 0u ? 1u : 0u;
     }
     peer_store(pub_mine, rd & 0xFFFFu);

@@ -80,9 +80,10 @@ constexpr uint32_t ENC_ORING = 32;       // staged output words per lane; word p
 
 // classes of the next 32 symbols of a lane, cheapest first (the wave takes the most expensive one any of its lanes needs)
 constexpr uint32_t CLS_FAST8 = 0;   // no model event possible, a dump every 8 symbols is enough
-constexpr uint32_t CLS_FAST4 = 1;   // no model event possible, skewed counts: a dump every 4 symbols
-constexpr uint32_t CLS_GENERAL = 2; // halving / MPS-LPS swap / division-shift change handled by selects, dump every 4
-constexpr uint32_t CLS_BITS = 3;    // bit at a time: first word of a channel, extreme counts
+constexpr uint32_t CLS_SPLIT = 1;   // as FAST8 but for ONE halving of the counts inside the word: coded in two parts (see below)
+constexpr uint32_t CLS_FAST4 = 2;   // no model event possible, skewed counts: a dump every 4 symbols
+constexpr uint32_t CLS_GENERAL = 3; // halving / MPS-LPS swap / division-shift change handled by selects, dump every 4
+constexpr uint32_t CLS_BITS = 4;    // bit at a time: first word of a channel, extreme counts
 
 template <bool ADAPTIVE, uint32_t ORING = ENC_ORING>
 struct BacEncoder
@@ -100,6 +101,13 @@ struct BacEncoder
   int32_t err;
   uint32_t safe;   // words that may still be coded in class `cls` before the preconditions have to be looked at again
   uint32_t cls;
+  // The symbols of the next word that the next word path codes: all 32 -- or, around a halving of the counts (CLS_SPLIT),
+  // first 0 .. h (h = the symbol whose update halves, bac.c:57), then, a step later, h+1 .. 31.  The other symbols of
+  // such a step are made no-ops -- a more probable symbol whose division magic is 0 leaves interval, counts and output
+  // untouched -- so the word path stays the straight-line fast one.  (The counts halve every 8191 symbols, and the 64
+  // lanes of a wave reach that point in different steps: handled by the general path, the wave spent a fifth of its
+  // steps there.)
+  uint32_t part_lo, part_hi;
 
   DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
   {
@@ -120,6 +128,8 @@ struct BacEncoder
     err = OK;
     safe = 0;
     cls = CLS_BITS;
+    part_lo = 0;
+    part_hi = 31;
   }
 
   DG_DEV uint32_t A() const
@@ -390,6 +400,17 @@ struct BacEncoder
       cls = CLS_FAST4;
       safe = w < w4 ? w : w4;
     }
+    else if (w_halve == 0u && tot <= MAX_FREQUENCY && diff >= 96u && lim8 >= tot + 160u)
+    {
+      // nothing but a halving in this word, with room to spare on both sides of it: the counts are in the top half of
+      // their range (one division shift before, and after -- cum[0] restarts at 8193 or 8194, never at a power of two),
+      // f1 - f2 >= 96 leaves >= 47 after the halving (no swap within 32 symbols), and 11 * f2 >= tot + 160 keeps the
+      // eight-symbol dump capacity for the halved counts (f2 -> at least f2 / 2, tot -> at most tot / 2 + 2)
+      cls = CLS_SPLIT;
+      safe = 0;
+      part_lo = 0;
+      part_hi = MAX_FREQUENCY - tot; // 0..31: the update of this symbol halves
+    }
     else
     {
       // the general word path copes with every model event; its groups of four need tot <= 128 * f2 throughout, and a
@@ -399,13 +420,41 @@ struct BacEncoder
     }
   }
 
+  // A word path is about to code the whole word after all (the wave took the general path for another lane's sake)
+  DG_DEV void whole_word()
+  {
+    part_lo = 0;
+    part_hi = 31;
+  }
+
+  // After a masked word path (encode_word<false, 8, true>) of a CLS_SPLIT lane.  Returns true when the word is complete.
+  // First part done: the update of symbol part_hi, which the word path applied as a plain count, is redone as
+  // UpdateModel does it (bac.c:57-80): halve, then count the symbol, then cum[0]++.
+  DG_DEV bool after_part(uint32_t word)
+  {
+    if (part_lo == 0u)
+    {
+      const uint32_t h = part_hi;
+      const uint32_t lps = ((word >> (31u - h)) & 1u) ^ mps;
+      const uint32_t c1h = c1 - lps;                     // cum[1] when symbol h was coded; cum[0] was MAX_FREQUENCY
+      c1 = (c1h >> 1) + 1u + lps;                        // :60-66 (f2 + 1) / 2 + 1, then :78 (no tie: see classify)
+      tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u; // (f1 + 1) / 2 + (f2 + 1) / 2 + 1, then :80
+      part_lo = h + 1u;
+      part_hi = 31;
+      if (h != 31u)
+        return false;
+    }
+    part_lo = 0;
+    return true;
+  }
+
   // The 32 division magics of the word that a lane would code next with a fast word path (cum[0] = tot .. tot+31).
   // The kernel fetches them from LDS right after a code step, so that the (bank-conflicting, per-lane scattered) reads
   // and their latency overlap the fill and drain phases instead of heading the next word.
   // the first quarter (see encode_word); all a static model ever needs
   DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
-    const uint32_t *const mg = magic + tot;
+    const uint32_t *const mg = magic + (tot - part_lo); // symbol i is coded with cum[0] = tot + (i - part_lo)
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 8u : 1u); i++)
       Mg[i] = mg[i];
@@ -413,7 +462,7 @@ struct BacEncoder
 
   DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
-    const uint32_t *const mg = magic + tot;
+    const uint32_t *const mg = magic + (tot - part_lo);
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
@@ -429,16 +478,20 @@ struct BacEncoder
   // GENERAL = true : the whole model update of bac.c:54-81 by selects; magics read from the table as the counts move.
   // DUMP: symbols between two dumps (8 or 4).
   // Returns 0, or -- when a carry ran past the held-back word -- the record for settle_word().
-  template <bool GENERAL, uint32_t DUMP>
+  // MASKED: only the symbols part_lo .. part_hi are coded, the others are no-ops (CLS_SPLIT; fast path only).
+  template <bool GENERAL, uint32_t DUMP, bool MASKED = false>
   DG_DEV uint32_t encode_word(uint32_t word, const uint32_t *magic, uint32_t (&Mg)[32])
   {
     static_assert(!GENERAL || ADAPTIVE, "the static model never needs the general path");
+    static_assert(!MASKED || (!GENERAL && ADAPTIVE), "parts of words are a matter of the adaptive fast path");
     static_assert(32 / DUMP <= 8, "the record of a word's hand-overs has 8 + 8 bits");
     uint32_t took = 0, ovf = 0;
     uint32_t mm = 0u - mps;                          // all ones when the MPS is the bit value 1
-    const uint32_t lw = GENERAL ? word : (word ^ mm); // fast: bit set = less probable symbol (the MPS cannot change)
+    // symbol i <-> bit 31 - i; a symbol that is not coded becomes a more probable one with magic 0
+    const uint32_t active = MASKED ? (0xFFFFFFFFu >> part_lo) & (0xFFFFFFFFu << (31u - part_hi)) : 0xFFFFFFFFu;
+    const uint32_t lw = GENERAL ? word : ((word ^ mm) & active); // fast: bit set = less probable symbol (the MPS cannot change)
     const uint32_t sh_word = div_shift(tot);
-    const uint32_t tot_word = tot;
+    const uint32_t tot_word = tot - (MASKED ? part_lo : 0u);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     // The 32 division magics of a fast word are scattered, bank-conflicting LDS reads: all at once they take a few hundred
     // cycles to land, and whoever needs an LDS answer meanwhile waits for the lot (LDS answers in order; the compiler
@@ -469,6 +522,8 @@ struct BacEncoder
       else
       {
         M = ADAPTIVE ? Mg[i] : Mg[0];
+        if (MASKED)
+          M &= (uint32_t)((int32_t)(active << i) >> 31);
         sh = sh_word;
       }
       const uint32_t a = (uint32_t)L;
@@ -516,7 +571,7 @@ struct BacEncoder
     if (GENERAL)
       mps = mm & 1u;
     else if (ADAPTIVE)
-      tot += 32u;
+      tot += MASKED ? part_hi - part_lo + 1u : 32u;
     return ovf != 0u ? took | 0x80000000u | (ovf << 16) : 0u; // nearly always 0: see settle_ripples()
   }
 };

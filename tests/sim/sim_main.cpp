@@ -171,10 +171,34 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
     f.classify();
     uint32_t cls = f.cls;
     if (cls <= CLS_GENERAL && ADAPTIVE && (r % 3) == 1)
+    {
       cls = CLS_GENERAL;
-    else if (cls <= CLS_FAST4 && (r % 3) == 2)
+      f.whole_word();
+    }
+    else if ((cls == CLS_FAST8 || cls == CLS_FAST4) && (r % 3) == 2)
       cls = CLS_FAST4;
-    if (cls == CLS_BITS)
+    if (cls == CLS_SPLIT)
+    {
+      // a halving word: two masked fast steps (one when the halving belongs to the last symbol), as the kernel does it
+      if constexpr (ADAPTIVE)
+      {
+        (*word_taken)++;
+        for (int part = 0; part < 2; part++)
+        {
+          uint32_t Mg[32];
+          f.fetch_magics_first(tab.data(), Mg);
+          const uint32_t record = f.template encode_word<false, 8, true>(word, tab.data(), Mg);
+          if (record != 0)
+          {
+            (*ripples)++;
+            f.settle_word(record, 4);
+          }
+          if (f.after_part(word))
+            break;
+        }
+      }
+    }
+    else if (cls == CLS_BITS)
     {
       for (uint32_t i = 0; i < 32; i++)
         f.encode_bit((word >> (31u - i)) & 1u, tab.data());

@@ -22,7 +22,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     res = {"lib": os.path.basename(dca.LIB_PATH), "kernel_ms": round(ms, 4), "bits_per_sample": round(float(bits.sum()) / (C_ * T), 3)}
     if "diag32" in dca.LIB_PATH:
         b = bits.cpu().numpy().reshape(-1, 64)
-        names = ["ballot_room", "fill", "loads+ballot_has", "fast_word", "slow_word", "park", "drain", "loop_top"]
+        names = ["publish", "general_or_fast4_word", "loads+ballot_has", "fast8_word", "masked_fast8_word", "bit_word", "drain", "loop_top"]
         res["cycles_per_wave"] = {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}
         res["total_cycles"] = int(b[:, :8].sum(axis=1).mean())
     print(json.dumps(res))
