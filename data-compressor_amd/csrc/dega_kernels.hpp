@@ -690,24 +690,62 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
       bool done = false;
       if (wave_any(can_word))
       {
-        const bool fast = wave_all(!can_word || dec.fast_ok());
-        if (can_word)
+        // Which word path?  The plain fast one when no lane's counts can do anything but count in this word; the masked
+        // fast one when what some lanes have is a halving (they decode the word in two parts, BacDecoder::split_ok);
+        // else the general one -- unless a lane is in the middle of such a word: it goes first, the others wait a step.
+        bool act = can_word;
+        const bool plain = wave_all(!can_word || dec.fast_ok());
+        bool masked = false;
+        if constexpr (ADAPTIVE)
+        {
+          if (!plain)
+          {
+            masked = wave_all(!can_word || dec.fast_ok() || dec.split_ok());
+            if (!masked && wave_any(can_word && dec.part_lo != 0u))
+            {
+              masked = true;
+              act = can_word && (dec.fast_ok() || dec.split_ok());
+            }
+          }
+        }
+        if (act)
         {
           const BacDecoder<ADAPTIVE> checkpoint = dec;
           uint32_t bits = 0;
-          if (fast)
+          bool whole = true;
+          if (plain)
             done = dec.template decode_word<false>(tab, Mnext, pre, bits);
           else if constexpr (ADAPTIVE)
-            done = dec.template decode_word<true>(tab, Mnext, pre, bits); // halving / swap / shift change somewhere in the wave
+          {
+            if (masked)
+            {
+              dec.begin_word();
+              done = dec.template decode_word<false, true>(tab, Mnext, pre, bits);
+              if (done)
+                whole = dec.after_part(bits);
+            }
+            else
+              done = dec.template decode_word<true>(tab, Mnext, pre, bits); // MPS/LPS swap, shift change, halving with little room
+          }
           if (done)
           {
-            bring[(wr % DEC_BRING) * 64u] = bits;
-            wr++;
-            seg_bits += 32;
+            if (whole)
+            {
+              bring[(wr % DEC_BRING) * 64u] = bits;
+              wr++;
+              seg_bits += 32;
+            }
           }
           else
+          {
+            // back to where the step began; what a first part has decoded is kept as the beginning of the bit-by-bit word
             dec = checkpoint;
+            nacc = dec.part_lo;
+            acc = nacc != 0u ? dec.part_bits >> (32u - nacc) : 0u;
+            dec.whole_word();
+          }
         }
+        done = done || (can_word && !act); // a lane that waits does not take the bit-by-bit path either
       }
       // Bit by bit -- the EOF symbol is in this word, or its symbols take more stream bits than the word path looks
       // ahead.  A word made this way may take several steps: a symbol is decoded only while the two stream words it may

@@ -818,6 +818,9 @@ struct BacDecoder
   uint32_t A, B, D;
   uint32_t c1, tot, mps;
   uint64_t bp; // stream bits consumed so far
+  // The symbols of the next word that the next masked word path decodes (as BacEncoder::part_lo / part_hi): all 32, or --
+  // around a halving of the counts -- first 0 .. h, then, a step later, h+1 .. 31; part_bits keeps the first part's bits.
+  uint32_t part_lo, part_hi, part_bits;
 
   DG_DEV void init()
   {
@@ -828,6 +831,9 @@ struct BacDecoder
     tot = 3;
     mps = 0;
     bp = 0;
+    part_lo = 0;
+    part_hi = 31;
+    part_bits = 0;
   }
 
   template <uint32_t IRING>
@@ -913,7 +919,7 @@ struct BacDecoder
 
   DG_DEV bool fast_ok() const
   {
-    bool ok = true;
+    bool ok = part_lo == 0u;
     if (ADAPTIVE)
     {
       ok = ok && tot + 32u <= MAX_FREQUENCY;
@@ -921,6 +927,58 @@ struct BacDecoder
       ok = ok && clz32(tot - 1u) == clz32(tot + 30u);
     }
     return ok;
+  }
+
+  // The next word holds a halving of the counts (bac.c:57) and nothing else the fast path cannot do -- or its first part
+  // has been decoded already: the masked word path takes it, in two steps (see BacEncoder::classify, CLS_SPLIT: the
+  // counts are in the top half of their range, and f1 - f2 >= 96 rules a swap out on both sides of the halving).
+  DG_DEV bool split_ok() const
+  {
+    return ADAPTIVE && (part_lo != 0u || (tot + 32u > MAX_FREQUENCY && tot <= MAX_FREQUENCY && tot + 1u >= 2u * c1 + 96u));
+  }
+
+  DG_DEV void begin_word() // before a masked word path: which symbols it decodes
+  {
+    if (part_lo == 0u)
+      part_hi = (tot + 32u > MAX_FREQUENCY) ? MAX_FREQUENCY - tot : 31u;
+  }
+
+  DG_DEV void whole_word()
+  {
+    part_lo = 0;
+    part_hi = 31;
+    part_bits = 0;
+  }
+
+  // After a masked word path that came through; `bits` = its symbols (the others zero).  Returns true when the word is
+  // complete (then `bits` is the whole word).  After the first part the update of symbol part_hi, which the word path
+  // applied as a plain count, is redone as UpdateModel does it: halve, count the symbol, cum[0]++ (BacEncoder::after_part).
+  DG_DEV bool after_part(uint32_t &bits)
+  {
+    bits |= part_bits;
+    if (part_lo == 0u && part_hi != 31u)
+    {
+      const uint32_t h = part_hi;
+      const uint32_t lps = ((bits >> (31u - h)) & 1u) ^ mps;
+      const uint32_t c1h = c1 - lps;
+      c1 = (c1h >> 1) + 1u + lps;
+      tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u;
+      part_lo = h + 1u;
+      part_hi = 31;
+      part_bits = bits;
+      return false;
+    }
+    if (part_lo == 0u && tot == MAX_FREQUENCY + 1u) // the halving belongs to the last symbol of the word
+    {
+      const uint32_t lps = (bits & 1u) ^ mps;
+      const uint32_t c1h = c1 - lps;
+      c1 = (c1h >> 1) + 1u + lps;
+      tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u;
+    }
+    part_lo = 0;
+    part_hi = 31;
+    part_bits = 0;
+    return true;
   }
 
   // 32 symbols, branch free.  Needs the words bp/32 .. bp/32 + 3 staged.  Returns false -- the caller restores its
@@ -931,21 +989,25 @@ struct BacDecoder
   // as BacEncoder::fetch_magics: the kernel issues these reads a phase early
   DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const // as BacEncoder::fetch_magics_first
   {
-    const uint32_t *const mg = magic + tot;
+    const uint32_t *const mg = magic + (tot - part_lo);
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 8u : 1u); i++)
       Mg[i] = mg[i];
   }
 
   // pre[0..3]: the stream's words bp/32 .. bp/32 + 3 (StreamWindow::word) -- the kernel reads them ahead of its ballots
-  template <bool GENERAL>
+  // MASKED: only the symbols part_lo .. part_hi are decoded, the others are no-ops (magic 0: a more probable symbol that
+  // changes nothing); bits_out holds zeros for them.
+  template <bool GENERAL, bool MASKED = false>
   DG_DEV bool decode_word(const uint32_t *magic, uint32_t (&Mg)[32], const uint32_t (&pre)[4], uint32_t &bits_out)
   {
+    static_assert(!MASKED || (!GENERAL && ADAPTIVE), "parts of words are a matter of the adaptive fast path");
+    const uint32_t active = MASKED ? (0xFFFFFFFFu >> part_lo) & (0xFFFFFFFFu << (31u - part_hi)) : 0xFFFFFFFFu;
     const uint32_t sh_fast = div_shift(tot);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
     const uint32_t k0 = (uint32_t)(bp >> 5);
     const uint32_t w0 = pre[0], w1 = pre[1], w2 = pre[2], w3 = pre[3];
-    const uint32_t tot_word = tot;
+    const uint32_t tot_word = tot - (MASKED ? part_lo : 0u);
     uint32_t off = (uint32_t)bp & 31u; // bit offset into w0:w1:w2:w3
     uint32_t off_group = off;
     uint32_t ahead = off ? (w0 << off) | (w1 >> (32u - off)) : w0; // next 32 stream bits, left aligned
@@ -969,6 +1031,8 @@ struct BacDecoder
       else
       {
         M = ADAPTIVE ? Mg[i] : Mg[0];
+        if (MASKED)
+          M &= (uint32_t)((int32_t)(active << i) >> 31);
         sh = sh_fast;
       }
       const uint32_t R = range_from_sum_plain(A + B);     // 1 .. 65536
@@ -1017,12 +1081,12 @@ struct BacDecoder
         ahead = o ? (lo << o) | (hi >> (32u - o)) : lo;
       }
     }
-    bits_out = GENERAL ? out : out ^ mm;
+    bits_out = GENERAL ? out : (out ^ mm) & active;
     bp = (uint64_t)k0 * 32u + off;
     if (GENERAL)
       mps = mm & 1u;
     else if (ADAPTIVE)
-      tot += 32u;
+      tot += MASKED ? part_hi - part_lo + 1u : 32u;
     return (int32_t)eof >= 0 && bad == 0;
   }
 };

@@ -147,3 +147,26 @@ def test_wide_workgroup_shape_on_golden_sets(sim):
             b2 = np.where(ok, bits, 0).astype(np.uint64)
             sim.sim_decode_wide(out.ctypes.data, cap, b2.ctypes.data, Cn, T, Cn, ad, y.ctypes.data, derr.ctypes.data)
             assert (derr[ok] == 0).all() and (y[:, ok] == x[:, ok]).all(), (name, tag)
+
+
+def test_long_channels_halvings_and_rare_symbol_runs(sim):
+    """Channels long enough for the counts to halve (bac.c:57) several times, at a different step in every lane -- the
+    words around a halving are coded in two masked parts -- plus channels that sit still for thousands of samples and then
+    jump: 32 rare symbols in a row take some 300 stream bits, more than a word path looks ahead."""
+    sim.sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    T, Cn = 4200, 70
+    step = rng.integers(1, 400, Cn)
+    x = np.cumsum(rng.integers(-1, 2, (T, Cn)) * rng.integers(0, 2, (T, Cn)) * step[None, :], axis=0) + 1000000
+    for c in range(0, Cn, 9):  # still, then wild
+        x[:, c] = 777
+        x[3000:3040, c] = rng.integers(0, 2 ** 31 - 1, 40)
+        x[3500:, c] = np.cumsum(rng.integers(-3, 4, T - 3500)) + 5000
+    x = x.astype(np.int32)
+    out, bits, err = sim_encode(sim, x, 1)
+    o2, b2, e2 = orc.encode_batch_tc(x, 1, cap=out.shape[1])
+    assert (err == e2).all() and (bits == b2).all() and (out == o2).all()
+    y = np.zeros((T, Cn), dtype=np.int32)
+    derr = np.zeros(Cn, dtype=np.int32)
+    sim.sim_decode(out.ctypes.data, out.shape[1], bits.ctypes.data, Cn, T, Cn, 1, y.ctypes.data, derr.ctypes.data)
+    assert (derr == 0).all() and (y == x).all()
