@@ -341,7 +341,10 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
   BacEncoder<ADAPTIVE, ORING> enc;
   enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u, oring_col);
   uint32_t rd = 0; // ring words coded so far
-  uint32_t peer;
+  // The filler's count as read one step ago: a word may only be read after a count that covers it, and waiting for the
+  // count before asking for the word would put two LDS round trips at the head of every step.  One step late costs
+  // nothing (the count only grows, the ring holds a dozen words).
+  uint32_t peer = peer_load(pub_peer);
   wave_priority<DG_ENC_CODE_PRIO>();
 
   DG_STAMP_DECL;
@@ -352,17 +355,18 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     // What a code step reads from LDS first -- the filler's count, the queued word and the first quarter of its division
     // magics -- is asked for here, ahead of the ballots that choose the word path; nothing LDS is carried around the loop
     // (a wait at the back edge would be a wait for the whole queue).
-    peer = peer_load(pub_peer);
+    const bool has = ((peer - rd) & 0xFFFFu) != 0u;
+    const bool all_done = (peer & ENC_PUB_DONE) != 0u;
     const uint32_t word = ring_col[(rd % RING) * 64u];
     uint32_t Mg[32];
     enc.fetch_magics_first(tab, Mg);
-    const bool has = ((peer - rd) & 0xFFFFu) != 0u;
+    peer = peer_load(pub_peer);
     const bool any_has = wave_any(has);
     DG_STAMP(2);
     if (!any_has)
     {
-      if (wave_all((peer & ENC_PUB_DONE) != 0u))
-        break; // all rows consumed and every queue drained
+      if (wave_all(all_done))
+        break; // all rows consumed and every queue drained ("done" comes in one word with the final count)
       wave_sleep<DG_ENC_CODE_SLEEP>();
       continue;
     }
@@ -857,6 +861,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   const bool full_wave = c_wave0 + 64u <= a.C;
   if (!wave_any(live))
     return; // a wave past the last channel
+  uint32_t peer = peer_load(pub_peer);
 
   // one decoded value -> memory, in the form the variant writes (rows past a failed channel's last sample: zeros)
   auto store_value = [&](uint32_t row, uint32_t lo, uint32_t hi, bool valid) {
@@ -881,25 +886,28 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   for (;;)
   {
     // ---- the next decoded word, if the partner has one and the window has room for it ---------------------------------
-    const uint32_t peer = peer_load(pub_peer);
+    // (the partner's count as read one pass ago: a word may only be read after a count that covers it, and this way the
+    // two reads go out together; the count only grows)
     const uint32_t avail = (peer - rd) & 0xFFFFu;
     const bool peer_done = (peer & DEC_PUB_DONE) != 0u;
     const bool got = !lane_final && avail != 0u && sp.has_room();
+    const uint32_t peer_seen = peer;
     {
       const uint32_t word = bring[(rd % DEC_BRING) * 64u];
-      const uint32_t part = (peer >> 16) & 31u;
+      peer = peer_load(pub_peer);
+      const uint32_t part = (peer_seen >> 16) & 31u;
       const uint32_t n = (peer_done && avail == 1u && part != 0u) ? part : 32u; // only the last word can be a partial one
       sp.push_word(got ? word : 0u, got ? n : 0u);
       rd += got ? 1u : 0u;
     }
-    final_in = !live || (peer_done && ((peer - rd) & 0xFFFFu) == 0u);
+    final_in = !live || (peer_done && ((peer_seen - rd) & 0xFFFFu) == 0u);
     peer_store(pub_mine, (rd & 0xFFFFu) | (lane_final ? DEC_PUB_FINAL : 0u));
     if (!wave_any(got || (final_in && !lane_final)) && !carry_over)
     {
       wave_sleep<DG_DEC_PARSE_SLEEP>();
       continue;
     }
-    if (final_in && (peer & DEC_PUB_BAD) != 0u && lane_err == OK)
+    if (final_in && (peer_seen & DEC_PUB_BAD) != 0u && lane_err == OK)
       lane_err = ERR_INVALID_FORMAT; // found by the arithmetic decoder: phantom bits, runaway stream
     const uint32_t t_before = t_lane, rows_before = rows_stored;
     const bool final_before = lane_final;
