@@ -278,10 +278,13 @@ static int check_job_shape(dega_hip_ctx *ctx, const Shape &j, size_t cap)
 }
 
 template <bool AD, bool NARROW, bool F32>
-static void encode_launch(size_t C, hipStream_t s, const EncodeArgs &a)
+static void encode_launch(bool wide, size_t C, hipStream_t s, const EncodeArgs &a)
 {
-  hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
-                     dim3(ENC_BLOCK), 0, s, a);
+  if (wide) // more channels than one coding wave per SIMD: 8 pairs of waves per workgroup, smaller rings
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 4, 16, 24, false, F32, 8>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
+                       dim3(ENC_BLOCK), 0, s, a);
 }
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
@@ -312,7 +315,7 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
   a.lo = -(float)((uint64_t)1 << (vs - 1));
   a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
-  (void)batch_C; // one workgroup shape for every batch size: pairs of waves, two per SIMD (dega_kernels.hpp)
+  const bool wide = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
   {
     LaunchTimer lt(ctx, 0, s);
     if (vs > 32) // 64-bit values
@@ -336,14 +339,14 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
       const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
       switch (sel)
       {
-        case 0: encode_launch<false, false, false>(j.C, s, a); break;
-        case 1: encode_launch<false, false, true>(j.C, s, a); break;
-        case 2: encode_launch<false, true, false>(j.C, s, a); break;
-        case 3: encode_launch<false, true, true>(j.C, s, a); break;
-        case 4: encode_launch<true, false, false>(j.C, s, a); break;
-        case 5: encode_launch<true, false, true>(j.C, s, a); break;
-        case 6: encode_launch<true, true, false>(j.C, s, a); break;
-        default: encode_launch<true, true, true>(j.C, s, a); break;
+        case 0: encode_launch<false, false, false>(wide, j.C, s, a); break;
+        case 1: encode_launch<false, false, true>(wide, j.C, s, a); break;
+        case 2: encode_launch<false, true, false>(wide, j.C, s, a); break;
+        case 3: encode_launch<false, true, true>(wide, j.C, s, a); break;
+        case 4: encode_launch<true, false, false>(wide, j.C, s, a); break;
+        case 5: encode_launch<true, false, true>(wide, j.C, s, a); break;
+        case 6: encode_launch<true, true, false>(wide, j.C, s, a); break;
+        default: encode_launch<true, true, true>(wide, j.C, s, a); break;
       }
     }
   }
@@ -352,9 +355,12 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
 }
 
 template <bool AD, bool NARROW, bool F32>
-static void decode_launch(size_t C, hipStream_t s, const DecodeArgs &a)
+static void decode_launch(bool wide, size_t C, hipStream_t s, const DecodeArgs &a)
 {
-  hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32>), dim3((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS)), dim3(DEC_BLOCK), 0, s, a);
+  if (wide)
+    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32, 8>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32>), dim3((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS)), dim3(DEC_BLOCK), 0, s, a);
 }
 
 static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, const Shape &j, size_t batch_C, void *x,
@@ -382,7 +388,7 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
   a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
   a.factor = j.factor;
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
-  (void)batch_C; // one workgroup shape for every batch size: pairs of waves, two per SIMD (dega_kernels.hpp)
+  const bool wide = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
   {
     LaunchTimer lt(ctx, 1, s);
     if (vs > 32)
@@ -406,14 +412,14 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
       const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
       switch (sel)
       {
-        case 0: decode_launch<false, false, false>(j.C, s, a); break;
-        case 1: decode_launch<false, false, true>(j.C, s, a); break;
-        case 2: decode_launch<false, true, false>(j.C, s, a); break;
-        case 3: decode_launch<false, true, true>(j.C, s, a); break;
-        case 4: decode_launch<true, false, false>(j.C, s, a); break;
-        case 5: decode_launch<true, false, true>(j.C, s, a); break;
-        case 6: decode_launch<true, true, false>(j.C, s, a); break;
-        default: decode_launch<true, true, true>(j.C, s, a); break;
+        case 0: decode_launch<false, false, false>(wide, j.C, s, a); break;
+        case 1: decode_launch<false, false, true>(wide, j.C, s, a); break;
+        case 2: decode_launch<false, true, false>(wide, j.C, s, a); break;
+        case 3: decode_launch<false, true, true>(wide, j.C, s, a); break;
+        case 4: decode_launch<true, false, false>(wide, j.C, s, a); break;
+        case 5: decode_launch<true, false, true>(wide, j.C, s, a); break;
+        case 6: decode_launch<true, true, false>(wide, j.C, s, a); break;
+        default: decode_launch<true, true, true>(wide, j.C, s, a); break;
       }
     }
   }

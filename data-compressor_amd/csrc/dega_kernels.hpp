@@ -83,12 +83,15 @@ struct EncodeArgs
   float factor, lo, hi;      // normalization factor; range of normalize.c:21 for the value size, rounded to float by the host compiler
 };
 
+// `symbols`: no channel of the batch codes more symbols than this (cum[0] starts at 3 and grows by one per symbol until
+// it halves at MAX_FREQUENCY): short channels need only the beginning of the table
 template <bool ADAPTIVE>
-DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab)
+DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols)
 {
   if (ADAPTIVE)
   {
-    for (uint32_t i = threadIdx.x; i < DIV_TABLE_SIZE; i += blockDim.x)
+    const uint32_t words = symbols + 68u < DIV_TABLE_SIZE ? (uint32_t)symbols + 68u : DIV_TABLE_SIZE; // + the fetch-ahead of a word
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
       tab[i] = gtab[i];
   }
   else if (threadIdx.x < 4)
@@ -518,8 +521,11 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
   }
 }
 
-template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING, bool W64 = false, bool F32IN = false>
-__global__ void __launch_bounds__(ENC_BLOCK) dega_encode_kernel(const EncodeArgs a)
+// PAIRS: 4 for batches of up to 64 Ki channels (one coding wave per SIMD is all there is); 8 -- with the smaller rings
+// <.., 4, 16, 24, ..> -- for larger ones: two coding waves per SIMD, and half as many workgroups to load the table.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING, bool W64 = false, bool F32IN = false,
+          uint32_t PAIRS = ENC_PAIRS>
+__global__ void __launch_bounds__(PAIRS * 128) dega_encode_kernel(const EncodeArgs a)
 {
   constexpr uint32_t LDS_ROWS = (W64 && !F32IN) ? 2 * ROWS : ROWS;
   static_assert(ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
@@ -528,14 +534,14 @@ __global__ void __launch_bounds__(ENC_BLOCK) dega_encode_kernel(const EncodeArgs
   // two published rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
   constexpr uint32_t PER_PAIR = (RING + ORING + LDS_ROWS + 2) * 64;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + ENC_PAIRS * PER_PAIR];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + PAIRS * PER_PAIR];
   static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
   uint32_t *const tab = lds;
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = wave_uniform(threadIdx.x >> 6);
-  const uint32_t pair = wave % ENC_PAIRS;
-  const bool codes = wave >= ENC_PAIRS;
+  const uint32_t pair = wave % PAIRS;
+  const bool codes = wave >= PAIRS;
   uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
   uint32_t *const ring_col = pair_lds + lane;                         // seg bits waiting to be coded
   uint32_t *const oring_col = pair_lds + RING * 64 + lane;            // coded words waiting to be stored
@@ -547,9 +553,9 @@ __global__ void __launch_bounds__(ENC_BLOCK) dega_encode_kernel(const EncodeArgs
     *pub_filler = 0;
     *pub_coder = 0;
   }
-  load_div_table<ADAPTIVE>(tab, a.div_magic); // ends with the workgroup's only barrier
+  load_div_table<ADAPTIVE>(tab, a.div_magic, (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
 
-  const size_t c_wave0 = (size_t)blockIdx.x * ENC_CHANNELS + pair * 64u;
+  const size_t c_wave0 = (size_t)blockIdx.x * (PAIRS * 64u) + pair * 64u;
   const size_t c = c_wave0 + lane;
   const bool live = c < a.C;
   if (!wave_any(live))
@@ -1061,30 +1067,31 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
 // passes), samples take two LDS slots.  F32OUT: the decoded value, read back as valuesize bits sign extended
 // (normalize.c:36-37), leaves as (float)n / factor (:38, IEEE division) -- float32 rows [T][ld] also for W64, no
 // integer intermediate in HBM.
-template <bool ADAPTIVE, bool NARROW = false, bool W64 = false, bool F32OUT = false>
-__global__ void __launch_bounds__(DEC_BLOCK) dega_decode_kernel(const DecodeArgs a)
+// PAIRS: 4 for batches of up to 64 Ki channels, 8 (with the short sample ring) for larger ones -- two coding waves per SIMD.
+template <bool ADAPTIVE, bool NARROW = false, bool W64 = false, bool F32OUT = false, uint32_t PAIRS = DEC_PAIRS>
+__global__ void __launch_bounds__(PAIRS * 128) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
   // decoded samples a lane may run ahead of the slowest lane of its wave before it has to wait for the row writer
-  constexpr uint32_t SRING = W64 ? DEC_SRING : 64;
+  constexpr uint32_t SRING = (W64 || PAIRS > 4) ? DEC_SRING : 64;
   constexpr uint32_t PER_PAIR = (DEC_IRING + 4 + DEC_BRING + 2 + (W64 ? 2 : 1) * (SRING + 1)) * 64; // + a spare sample slot
-  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + DEC_PAIRS * PER_PAIR];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + PAIRS * PER_PAIR];
   static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
   uint32_t *const tab = lds;
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = wave_uniform(threadIdx.x >> 6);
-  const uint32_t pair = wave % DEC_PAIRS;
-  const bool parses = wave >= DEC_PAIRS;
+  const uint32_t pair = wave % PAIRS;
+  const bool parses = wave >= PAIRS;
   uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
   if (!parses) // nothing handed over, nothing taken
   {
     pair_lds[(DEC_IRING + 4 + DEC_BRING) * 64 + lane] = 0;
     pair_lds[(DEC_IRING + 4 + DEC_BRING + 1) * 64 + lane] = 0;
   }
-  load_div_table<ADAPTIVE>(tab, a.div_magic); // ends with the workgroup's only barrier
+  load_div_table<ADAPTIVE>(tab, a.div_magic, (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
 
-  const size_t c_wave0 = (size_t)blockIdx.x * DEC_CHANNELS + pair * 64u;
+  const size_t c_wave0 = (size_t)blockIdx.x * (PAIRS * 64u) + pair * 64u;
   const size_t c = c_wave0 + lane;
   const bool live = c < a.C;
   if (parses)

@@ -1074,6 +1074,8 @@ struct BacDecoder
       }
       if ((i & 7u) == 7u) // rebuild the look-ahead from the staged words (8 symbols rarely take more than 32 bits: else redo)
       {
+        DG_MATERIALISE(out); // (left alone hipcc gathers the 32 symbols' bits and their D's at the end of the word: 60 live registers)
+        DG_MATERIALISE(eof);
         bad |= (off - off_group > 32u || off > 95u) ? 1u : 0u;
         off_group = off;
         const uint32_t o = off & 31u;

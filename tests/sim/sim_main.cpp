@@ -284,23 +284,23 @@ extern "C" __attribute__((visibility("default"))) int sim_encode_wide(const int3
 {
   static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), 32u};
-  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)); // (the small-ring shape: 4 rows per batch, 16 / 24 ring words)
+  const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 4 rows per batch, 16 / 24 ring words
   if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 4, 16, 24>, grid, dim3(ENC_BLOCK), a);
+    sim::launch(dega_encode_kernel<true, false, 4, 16, 24, false, false, 8>, grid, dim3(1024), a);
   else
-    sim::launch(dega_encode_kernel<false, false, 4, 16, 24>, grid, dim3(ENC_BLOCK), a);
+    sim::launch(dega_encode_kernel<false, false, 4, 16, 24, false, false, 8>, grid, dim3(1024), a);
   return 0;
 }
 
 extern "C" __attribute__((visibility("default"))) int sim_decode_wide(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
-  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr, 32u}; // (one decode shape since the paired waves)
-  const dim3 grid((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS));
+  DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr, 32u};
+  const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 16-sample ring
   if (adaptive)
-    sim::launch(dega_decode_kernel<true>, grid, dim3(DEC_BLOCK), a);
+    sim::launch(dega_decode_kernel<true, false, false, false, 8>, grid, dim3(1024), a);
   else
-    sim::launch(dega_decode_kernel<false>, grid, dim3(DEC_BLOCK), a);
+    sim::launch(dega_decode_kernel<false, false, false, false, 8>, grid, dim3(1024), a);
   return 0;
 }
 
