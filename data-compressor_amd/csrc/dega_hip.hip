@@ -664,7 +664,7 @@ extern "C" int dega_hip_lzmh_encode_dev(dega_hip_ctx *ctx, const uint8_t *in, si
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 2, s);
-    hipLaunchKernelGGL(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_ENC_THREADS), 0, s, a);
   }
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;

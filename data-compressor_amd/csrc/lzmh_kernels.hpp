@@ -19,7 +19,7 @@
 //   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass, and each is
 //            measured against the 16 input bytes held in registers (all LDS reads of a pass in flight together);
 //            `len > best` in that order keeps the nearest of equals.
-// Window: 448 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for the whole wave when a lane
+// Window: 432 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for the whole wave when a lane
 // runs out of look-ahead (every ~270 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count})
 // and four staged output words per lane are in LDS as well: 152 KiB per workgroup, one workgroup per CU.
 //
@@ -38,8 +38,10 @@ constexpr uint32_t LZ_LIST = 48;        // HUFFLIST_LENGTH, lzmh.c:67
 constexpr uint32_t LZ_TREE = 19;        // HUFFTREE_LENGTH, lzmh.c:70
 
 constexpr uint32_t LZ_BLOCK = 256;
-constexpr uint32_t LZ_WIN_DW = 112;              // window dwords per lane (448 bytes)
+constexpr uint32_t LZ_WIN_DW = 108;              // window dwords per lane (432 bytes)
 constexpr uint32_t LZ_WIN_BYTES = 4 * LZ_WIN_DW;
+// a freshly loaded window (history, up to 15 bytes of alignment) must hold the longest match, or a step could never end
+static_assert(LZ_WIN_BYTES >= LZ_HISTORY + 15 + LZ_MAX_LENGTH && LZ_WIN_DW % 4 == 0, "window too small");
 constexpr uint32_t LZ_POP = 5;                   // candidates of one mask register handled per pass
 constexpr uint32_t LZ_AHEAD = 48;                // look-ahead a step needs in the window: 24 bytes in registers + slack
 constexpr uint32_t LZ_SYM_DW = LZ_LIST / 4, LZ_CNT_DW = LZ_LIST / 2, LZ_STAGE_DW = 4;
@@ -174,47 +176,67 @@ DG_DEV uint32_t lz_list_position(uint32_t t, uint32_t &len)
   return p;
 }
 
-__global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a)
-{
-  __shared__ uint32_t lds[LZ_LDS_DW];
-  const uint32_t tid = threadIdx.x;
-  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + tid;
-  const bool live = c < a.C;
-  uint32_t *const win = lds + LZ_OFF_WIN + tid;                                  // dword d of this lane: win[d * LZ_BLOCK]
-  uint8_t *const win8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_WIN + tid);     // byte b: win8[(b >> 2) * 4 * LZ_BLOCK + (b & 3)]
-  uint32_t *const symd = lds + LZ_OFF_SYM + tid;
-  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_SYM + tid);
-  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZ_OFF_CNT + tid);  // count i: cnt16[(i >> 1) * 2 * LZ_BLOCK + (i & 1)]
-  uint32_t *const stage = lds + LZ_OFF_STAGE + tid;
+// The kernel runs as PAIRS of waves, like the DEGA kernels: of 64 channels' two waves (wave p and wave p + 4 of the
+// workgroup, which the CU places on the same SIMD) the first SEARCHES -- window, candidates, the longest match -- and
+// hands one token per step (match length | offset | the byte at P) to the second through a small LDS ring; the second
+// CODES: recent-offset cache, frequency list, bits, output.  The parse does not depend on the coder's state (greedy
+// longest match, nearest of equals), so the searcher never waits for anything but ring room, and each wave fills the
+// issue slots the other leaves empty while it waits for LDS.
+//   searcher publishes: tokens written (mod 2^16) | no more will come << 24
+//   coder publishes:    tokens taken (mod 2^16)   | the lane wants no more (output full) << 16
+#ifndef LZ_TOK_RING_OVERRIDE
+constexpr uint32_t LZ_TOK_RING = 8;
+#else
+constexpr uint32_t LZ_TOK_RING = LZ_TOK_RING_OVERRIDE; // (stress builds of the emulator)
+#endif
+constexpr uint32_t LZ_PUB_DONE = 1u << 24, LZ_PUB_FINAL = 1u << 16;
+constexpr uint32_t LZ_OFF_TOK = LZ_LDS_DW, LZ_OFF_PUB = LZ_OFF_TOK + LZ_TOK_RING * LZ_BLOCK, LZ_ENC_LDS_DW = LZ_OFF_PUB + 2 * LZ_BLOCK;
+static_assert(LZ_ENC_LDS_DW * 4 <= 160 * 1024, "LDS budget of one CU");
+constexpr uint32_t LZ_ENC_THREADS = 2 * LZ_BLOCK; // LZ_BLOCK channels per workgroup, two waves per 64 of them
+
 #define LZ_WIN8(b) win8[((b) >> 2) * (4u * LZ_BLOCK) + ((b) & 3u)]
 #define LZ_SYM8(i) sym8[((i) >> 2) * (4u * LZ_BLOCK) + ((i) & 3u)]
 #define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
 
+// ---- the searching wave ----------------------------------------------------------------------------------------------
+DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
+{
+  uint32_t *const win = lds + LZ_OFF_WIN + slot;                                  // dword d of this lane: win[d * LZ_BLOCK]
+  uint8_t *const win8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_WIN + slot);     // byte b: win8[(b >> 2) * 4 * LZ_BLOCK + (b & 3)]
+  uint32_t *const tok = lds + LZ_OFF_TOK + slot;
+  uint32_t *const pub_mine = lds + LZ_OFF_PUB + slot;
+  const uint32_t *const pub_peer = pub_mine + LZ_BLOCK;
+
   const uint64_t n64 = live ? a.in_len[c] : 0;
   const uint32_t n = (uint32_t)n64;
   const uint8_t *const src = a.in + (live ? c : 0) * a.stride;
-  uint8_t *const dst = a.out + (live ? c : 0) * a.cap;
-  int32_t err = (n64 > a.stride || n64 > 0x7FFFFFF0ull) ? ERR_INVALID_VALUE : OK;
+  const bool bad = n64 > a.stride || n64 > 0x7FFFFFF0ull;
   // lzmh.c:161-174: exactly one ring of input wraps the write index onto the read index and the main loop never runs
-  const uint32_t n_eff = (n == LZ_RING || err != OK) ? 0u : n;
+  const uint32_t n_eff = (n == LZ_RING || bad) ? 0u : n;
 
   uint32_t P = 0;          // bytes consumed
   int32_t base = -128;     // absolute position of window byte 0 (multiple of 16)
-  uint32_t mru = 0;        // the four most recent offsets, most recent in the low byte (lzmh.c:135)
-  uint32_t nlist = 0;      // used entries of the frequency list
-  uint64_t acc = 0;        // output bits, MSB first
-  uint32_t nacc = 0, staged = 0, pos = 0; // bits in acc, words in stage[], words stored
+  uint32_t wr = 0;         // tokens handed over
   bool reload = true;
+  bool stop = false;       // the coder wants no more of this channel
   DG_STAMP_DECL;
 
   for (;;)
   {
-    const bool active = P < n_eff && err == OK;
-    if (!wave_any(active))
+    const uint32_t peer = peer_load(pub_peer);
+    stop = stop || (peer & LZ_PUB_FINAL) != 0u;
+    const bool todo = P < n_eff && !stop;
+    if (!wave_any(todo))
       break;
+    const bool active = todo && ((wr - peer) & 0xFFFFu) < LZ_TOK_RING;
+    if (!wave_any(active))
+    {
+      wave_sleep<1>();
+      continue;
+    }
     DG_STAMP(7);
 
-    // ---- window: every active lane of the wave reloads [P-128 (rounded down to 16), +448) when one lane needs it ----
+    // ---- window: every active lane of the wave reloads [P-128 (rounded down to 16), +432) when one lane needs it ----
     if (wave_any(active && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
     {
       DG_STAMP(0);
@@ -237,8 +259,8 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
           win[(4u * k + 2u) * LZ_BLOCK] = v2;
           win[(4u * k + 3u) * LZ_BLOCK] = v3;
         }
+        reload = false; // (a lane that sits this step out for want of ring room keeps its request)
       }
-      reload = false;
       DG_STAMP(6);
     }
 
@@ -334,6 +356,65 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
       reload = true;
     const bool emit = active && !again;
 
+    if (emit)
+    {
+      tok[(wr % LZ_TOK_RING) * LZ_BLOCK] = (best << 16) | (besto << 8) | (T0 & 0xFFu);
+      wr++;
+      P += best >= 3u ? best : 1u;
+    }
+    peer_store(pub_mine, (wr & 0xFFFFu) | ((P >= n_eff || stop) ? LZ_PUB_DONE : 0u));
+    DG_STAMP(3);
+  }
+  peer_store(pub_mine, (wr & 0xFFFFu) | LZ_PUB_DONE);
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+  if (live)
+  {
+    if ((slot & 63u) < 8)
+      a.out_bits[c] = stamp_sum[slot & 63u];
+    else if ((slot & 63u) < 16)
+      a.out_bits[c] = stamp_cnt[(slot & 63u) - 8];
+  }
+#endif
+}
+
+// ---- the coding wave -------------------------------------------------------------------------------------------------
+DG_DEV void lzmh_coding_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
+{
+  uint32_t *const symd = lds + LZ_OFF_SYM + slot;
+  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZ_OFF_SYM + slot);
+  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZ_OFF_CNT + slot);  // count i: cnt16[(i >> 1) * 2 * LZ_BLOCK + (i & 1)]
+  uint32_t *const stage = lds + LZ_OFF_STAGE + slot;
+  const uint32_t *const tok = lds + LZ_OFF_TOK + slot;
+  const uint32_t *const pub_peer = lds + LZ_OFF_PUB + slot;
+  uint32_t *const pub_mine = lds + LZ_OFF_PUB + LZ_BLOCK + slot;
+
+  const uint64_t n64 = live ? a.in_len[c] : 0;
+  uint8_t *const dst = a.out + (live ? c : 0) * a.cap;
+  int32_t err = (n64 > a.stride || n64 > 0x7FFFFFF0ull) ? ERR_INVALID_VALUE : OK;
+
+  uint32_t mru = 0;        // the four most recent offsets, most recent in the low byte (lzmh.c:135)
+  uint32_t nlist = 0;      // used entries of the frequency list
+  uint64_t acc = 0;        // output bits, MSB first
+  uint32_t nacc = 0, staged = 0, pos = 0; // bits in acc, words in stage[], words stored
+  uint32_t rd = 0;         // tokens taken
+  uint32_t peer = peer_load(pub_peer); // (one pass old when it is used: see the DEGA coding waves)
+
+  for (;;)
+  {
+    const bool emit = ((peer - rd) & 0xFFFFu) != 0u && err == OK;
+    const bool peer_done = (peer & LZ_PUB_DONE) != 0u;
+    const uint32_t token = tok[(rd % LZ_TOK_RING) * LZ_BLOCK];
+    peer = peer_load(pub_peer);
+    if (!wave_any(emit))
+    {
+      if (wave_all(peer_done || err != OK))
+        break;
+      wave_sleep<2>();
+      continue;
+    }
+    const uint32_t best = token >> 16, besto = (token >> 8) & 0xFFu, T0 = token & 0xFFu;
+    rd += emit ? 1u : 0u;
+
     // ---- code the step (lzmh.c:216-340) ----
     uint32_t code = 0, codelen = 0;
     const bool lit = emit && best < 3;
@@ -384,9 +465,7 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         code = (code << 10) | 0x300u | (best - 19u);
         codelen += 10;
       }
-      P += best;
     }
-    DG_STAMP(3);
     if (wave_any(lit))
     {
       // literal: position of the symbol in the frequency list (lzmh.c:285-333)
@@ -457,11 +536,10 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
           code = sym; // 00 + byte
           codelen = 10;
         }
-        P += 1;
       }
     }
 
-    DG_STAMP(4);
+
     // ---- output: bits -> 64-bit accumulator -> staged words in LDS -> 16-byte stores ----
     if (emit)
     {
@@ -491,8 +569,9 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         staged = 0;
       }
     }
-    DG_STAMP(5);
+    peer_store(pub_mine, (rd & 0xFFFFu) | (err != OK ? LZ_PUB_FINAL : 0u));
   }
+  peer_store(pub_mine, (rd & 0xFFFFu) | LZ_PUB_FINAL);
 
   // ---- finish: the staged words and the partial word, zero padded ----
   if (live)
@@ -511,19 +590,40 @@ __global__ void __launch_bounds__(256) lzmh_encode_kernel(const LzmhEncodeArgs a
         bits = 32ull * (pos + staged) + nacc;
       }
     }
-    a.out_bits[c] = bits;
     a.err[c] = err;
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-    if ((tid & 63u) < 8)
-      a.out_bits[c] = stamp_sum[tid & 63u];
-    else if ((tid & 63u) < 16)
-      a.out_bits[c] = stamp_cnt[(tid & 63u) - 8];
+    (void)bits; // diagnostic build: the searching wave dumps its stamps over out_bits
+#else
+    a.out_bits[c] = bits;
 #endif
   }
+}
+
+__global__ void __launch_bounds__(LZ_ENC_THREADS) lzmh_encode_kernel(const LzmhEncodeArgs a)
+{
+  __shared__ uint32_t lds[LZ_ENC_LDS_DW];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = wave_uniform(threadIdx.x >> 6);
+  const uint32_t slot = (wave % 4u) * 64u + lane; // the channel's column in every LDS array
+  const bool codes = wave >= 4u;
+  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + slot;
+  const bool live = c < a.C;
+  if (!codes) // nothing handed over, nothing taken
+  {
+    lds[LZ_OFF_PUB + slot] = 0;
+    lds[LZ_OFF_PUB + LZ_BLOCK + slot] = 0;
+  }
+  __syncthreads();
+  if (!wave_any(live))
+    return;
+  if (codes)
+    lzmh_coding_wave(a, lds, slot, c, live);
+  else
+    lzmh_searching_wave(a, lds, slot, c, live);
+}
 #undef LZ_WIN8
 #undef LZ_SYM8
 #undef LZ_CNT
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LZMH decode (DCLib/src/lzmh.c:383-574), one lane per channel.  The decoder is a 32-bit code register that is topped up

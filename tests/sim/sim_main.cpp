@@ -261,7 +261,7 @@ extern "C" __attribute__((visibility("default"))) int sim_fast_vs_slow(uint64_t 
 extern "C" __attribute__((visibility("default"))) int sim_lzmh_encode(const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
 {
   LzmhEncodeArgs a{in, stride, in_len, C, out, cap, bits, err};
-  sim::launch(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
+  sim::launch(lzmh_encode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_ENC_THREADS), a);
   return 0;
 }
 

@@ -139,3 +139,19 @@ def test_lzmh_render_kernel(sim):
     for c in range(5):
         want = "".join("%d.%02d\n" % (v // 100, v % 100) for v in x[:, c].tolist()).encode()
         assert err[c] == 0 and out[c, : int(lens[c])].tobytes() == want
+
+
+@pytest.mark.timeout(600)
+def test_lzmh_longest_match_at_every_window_alignment(sim):
+    """A match of the maximum length (274) that begins at every position modulo 16: the window a lane reloads starts at
+    (P - 128) rounded down to 16, and whatever the alignment it has to hold the whole match, or the step is retried for ever."""
+    rng = np.random.default_rng(3)
+    strings = []
+    for k in range(32):
+        head = bytes(rng.integers(0, 256, 130 + k, dtype=np.uint8))
+        strings.append(head + bytes([65 + k]) * (700 + 3 * k) + head[:40])
+    out, bits, err = sim_encode(sim, strings)
+    assert (err == 0).all()
+    for i, s in enumerate(strings):
+        r, b, n = orc.stage("lzmh", True, s, 8 * len(s))
+        assert r == 0 and int(bits[i]) == n and out[i, : (n + 7) // 8].tobytes() == b[: (n + 7) // 8], (i, len(s))
