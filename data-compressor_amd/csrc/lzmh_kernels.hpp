@@ -219,6 +219,16 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
   uint32_t wr = 0;         // tokens handed over
   bool reload = true;
   bool stop = false;       // the coder wants no more of this channel
+  // A step in the making: the candidates of a step are measured five per pass of the wave's loop, and a lane whose step
+  // has more of them (a line start of the ASCII workload has 16, the average step 2) simply takes more passes -- the
+  // other lanes go on to their next steps meanwhile.  (In one lockstep step per lane the wave measured 25 candidates
+  // per step for an average lane that has 2.)
+  bool verifying = false;
+  uint32_t cm[5] = {0, 0, 0, 0, 0}; // candidates left: bit i of the 132-bit mask = window position 4 * wd0 + i
+  uint32_t best = 2, besto = 0;
+  uint32_t T0 = 0, T1 = 0, T2 = 0, T3 = 0; // the next 16 input bytes
+  uint32_t rel = LZ_HISTORY, wd0 = 0, lim = 0, maxlen = 0;
+  bool search = false;
   DG_STAMP_DECL;
 
   for (;;)
@@ -228,19 +238,19 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
     const bool todo = P < n_eff && !stop;
     if (!wave_any(todo))
       break;
-    const bool active = todo && ((wr - peer) & 0xFFFFu) < LZ_TOK_RING;
-    if (!wave_any(active))
+    const bool start = todo && !verifying && ((wr - peer) & 0xFFFFu) < LZ_TOK_RING; // begins a step in this pass
+    if (!wave_any(start || (todo && verifying)))
     {
       wave_sleep<1>();
       continue;
     }
     DG_STAMP(7);
 
-    // ---- window: every active lane of the wave reloads [P-128 (rounded down to 16), +432) when one lane needs it ----
-    if (wave_any(active && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
+    // ---- window: every lane that begins a step reloads [P-128 (rounded down to 16), +432) when one of them needs it ----
+    if (wave_any(start && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
     {
       DG_STAMP(0);
-      if (active)
+      if (start)
       {
         base = (int32_t)((P - LZ_HISTORY) & ~15u);
 #pragma unroll
@@ -248,7 +258,7 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
         {
           const int32_t at = base + (int32_t)(16u * k);
           // rows before the start of the channel (at < 0) and past the end of its row read row 0 / the last 16 bytes
-          // instead and are zeroed: no branch around the load, so the 28 loads are in flight together
+          // instead and are zeroed: no branch around the load, so the 27 loads are in flight together
           const bool inside = at >= 0 && (size_t)at + 16u <= a.stride;
           const size_t from = inside ? (size_t)at : 0u;
           const lz_u32x4 v = *reinterpret_cast<const lz_u32x4 *>(src + from);
@@ -259,109 +269,136 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
           win[(4u * k + 2u) * LZ_BLOCK] = v2;
           win[(4u * k + 3u) * LZ_BLOCK] = v3;
         }
-        reload = false; // (a lane that sits this step out for want of ring room keeps its request)
+        reload = false; // (a lane that does not begin a step in this pass keeps its request)
       }
       DG_STAMP(6);
     }
 
     DG_STAMP(0);
-    // ---- bounds of this step (see the header) ----
-    const uint32_t maxoff = P < LZ_HISTORY ? P : LZ_HISTORY;
-    const uint32_t wabs_raw = (P > LZ_HISTORY ? P - LZ_HISTORY : 0u) + LZ_RING;
-    const uint32_t wabs = wabs_raw < n ? wabs_raw : n;
-    uint32_t maxlen = wabs - P;
-    maxlen = maxlen > LZ_MAX_LENGTH ? LZ_MAX_LENGTH : maxlen;
-    const uint32_t in_window = (uint32_t)(base + (int32_t)LZ_WIN_BYTES - (int32_t)P); // bytes of look-ahead the window holds
-    const uint32_t lim = maxlen < in_window ? maxlen : in_window;
-    const bool search = active && maxoff > 0 && maxlen > 2;
+    // ---- a new step: its bounds (see the header) and phase 1, the 3-byte candidates among the last 132 positions.
+    //      Worked out by every lane, taken over by those that begin a step ----
+    {
+      const uint32_t maxoff = P < LZ_HISTORY ? P : LZ_HISTORY;
+      const uint32_t wabs_raw = (P > LZ_HISTORY ? P - LZ_HISTORY : 0u) + LZ_RING;
+      const uint32_t wabs = wabs_raw < n ? wabs_raw : n;
+      uint32_t maxlen_n = wabs - P;
+      maxlen_n = maxlen_n > LZ_MAX_LENGTH ? LZ_MAX_LENGTH : maxlen_n;
+      const uint32_t in_window = (uint32_t)(base + (int32_t)LZ_WIN_BYTES - (int32_t)P); // bytes of look-ahead the window holds
+      const uint32_t lim_n = maxlen_n < in_window ? maxlen_n : in_window;
+      const bool search_n = start && maxoff > 0 && maxlen_n > 2;
 
-    // ---- phase 1: 3-byte candidates among the last 132 positions ----
-    const uint32_t rel = active ? (uint32_t)((int32_t)P - base) : LZ_HISTORY; // window byte index of position P (128..400)
-    const uint32_t wd0 = (rel - LZ_HISTORY) >> 2;                             // first history dword
-    const uint32_t s = rel & 3u;
-    uint32_t d[38];
+      const uint32_t rel_n = start ? (uint32_t)((int32_t)P - base) : LZ_HISTORY; // window byte index of position P (128..400)
+      const uint32_t wd0_n = (rel_n - LZ_HISTORY) >> 2;                          // first history dword
+      const uint32_t s = rel_n & 3u;
+      uint32_t d[38];
 #pragma unroll
-    for (uint32_t j = 0; j < 38; j++)
-      d[j] = win[(wd0 + j) * LZ_BLOCK];
-    const uint32_t T0 = lz_alignbyte(d[33], d[32], s), T1 = lz_alignbyte(d[34], d[33], s), T2 = lz_alignbyte(d[35], d[34], s),
-                   T3 = lz_alignbyte(d[36], d[35], s);
-    const uint32_t A0 = (T0 & 0xFFu) * 0x01010101u, A1 = ((T0 >> 8) & 0xFFu) * 0x01010101u, A2 = ((T0 >> 16) & 0xFFu) * 0x01010101u;
-    uint32_t cm[5] = {0, 0, 0, 0, 0}; // bit i of the 132-bit mask: window position 4*wd0 + i starts a 3-byte match
+      for (uint32_t j = 0; j < 38; j++)
+        d[j] = win[(wd0_n + j) * LZ_BLOCK];
+      const uint32_t U0 = lz_alignbyte(d[33], d[32], s), U1 = lz_alignbyte(d[34], d[33], s), U2 = lz_alignbyte(d[35], d[34], s),
+                     U3 = lz_alignbyte(d[36], d[35], s);
+      const uint32_t A0 = (U0 & 0xFFu) * 0x01010101u, A1 = ((U0 >> 8) & 0xFFu) * 0x01010101u, A2 = ((U0 >> 16) & 0xFFu) * 0x01010101u;
+      uint32_t cn[5] = {0, 0, 0, 0, 0}; // bit i of the 132-bit mask: window position 4*wd0 + i starts a 3-byte match
 #pragma unroll
-    for (uint32_t j = 0; j < 33; j++)
-    {
-      const uint32_t y = (d[j] ^ A0) | (lz_alignbyte(d[j + 1], d[j], 1) ^ A1) | (lz_alignbyte(d[j + 1], d[j], 2) ^ A2);
-      cm[j >> 3] = lz_shift_in_nibble(cm[j >> 3], lz_gather_flags(lz_zero_bytes_approx(y)));
-    }
-    cm[4] >>= 28;
-    {
-      // position i is offset 128 + s - i: valid offsets are 1..maxoff
-      const int32_t lo = (int32_t)(LZ_HISTORY + s - maxoff);
-      const uint32_t keep = search ? 0xFFFFFFFFu : 0u;
-      cm[0] &= lz_mask_from(lo) & keep;
-      cm[1] &= lz_mask_from(lo - 32) & keep;
-      cm[2] &= lz_mask_from(lo - 64) & keep;
-      cm[3] &= lz_mask_from(lo - 96) & keep;
-      cm[4] &= ((1u << s) - 1u) & keep;
+      for (uint32_t j = 0; j < 33; j++)
+      {
+        const uint32_t y = (d[j] ^ A0) | (lz_alignbyte(d[j + 1], d[j], 1) ^ A1) | (lz_alignbyte(d[j + 1], d[j], 2) ^ A2);
+        cn[j >> 3] = lz_shift_in_nibble(cn[j >> 3], lz_gather_flags(lz_zero_bytes_approx(y)));
+      }
+      cn[4] >>= 28;
+      {
+        // position i is offset 128 + s - i: valid offsets are 1..maxoff
+        const int32_t lo = (int32_t)(LZ_HISTORY + s - maxoff);
+        const uint32_t keep = search_n ? 0xFFFFFFFFu : 0u;
+        cn[0] &= lz_mask_from(lo) & keep;
+        cn[1] &= lz_mask_from(lo - 32) & keep;
+        cn[2] &= lz_mask_from(lo - 64) & keep;
+        cn[3] &= lz_mask_from(lo - 96) & keep;
+        cn[4] &= ((1u << s) - 1u) & keep;
+      }
+      if (start)
+      {
+#pragma unroll
+        for (uint32_t r = 0; r < 5; r++)
+          cm[r] = cn[r];
+        T0 = U0;
+        T1 = U1;
+        T2 = U2;
+        T3 = U3;
+        rel = rel_n;
+        wd0 = wd0_n;
+        lim = lim_n;
+        maxlen = maxlen_n;
+        search = search_n;
+        best = 2;
+        besto = 0;
+        verifying = true;
+      }
     }
 
     DG_STAMP(1);
-    // ---- phase 2: candidates nearest first, LZ_POP of a mask register per pass, every one measured against the 16 input
-    // bytes held in registers (5 window dwords each, all reads of a pass in flight together: one LDS latency per pass);
-    // `len > best` in that order keeps the nearest of equals, like the reference's ascending scan (:196-214) ----
-    uint32_t best = 2, besto = 0;
-#pragma unroll
-    for (int r = 4; r >= 0; r--)
+    // ---- phase 2, one pass: up to LZ_POP candidates of the nearest mask register that still has some, nearest first, every
+    // one measured against the 16 input bytes held in registers (5 window dwords each, all reads of the pass in flight
+    // together: one LDS latency); `len > best` in that order keeps the nearest of equals, like the reference's ascending
+    // scan (:196-214) ----
+    if (wave_any(verifying && best < lim && (cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) != 0u))
     {
-      while (wave_any(cm[r] != 0 && best < lim))
+      const bool go = verifying && best < lim;
+      const uint32_t r32 = cm[4] != 0u ? 128u : cm[3] != 0u ? 96u : cm[2] != 0u ? 64u : cm[1] != 0u ? 32u : 0u; // 32 * the register
+      uint32_t m = cm[4] != 0u ? cm[4] : cm[3] != 0u ? cm[3] : cm[2] != 0u ? cm[2] : cm[1] != 0u ? cm[1] : cm[0];
+      m = go ? m : 0u;
+      uint32_t qb[LZ_POP], e[LZ_POP][5];
+      uint32_t has = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < LZ_POP; k++)
       {
-        uint32_t m = best < lim ? cm[r] : 0u;
-        uint32_t qb[LZ_POP], e[LZ_POP][5];
-        uint32_t has = 0;
+        has |= m != 0 ? 1u << k : 0u;
+        const uint32_t bit = 31u - clz32(m | 1u);
+        m &= ~(1u << bit);
+        qb[k] = 4u * wd0 + r32 + bit; // window byte index of the candidate (a valid address also when there is none)
+        const uint32_t qd = qb[k] >> 2;
 #pragma unroll
-        for (uint32_t k = 0; k < LZ_POP; k++)
+        for (uint32_t j = 0; j < 5; j++)
+          e[k][j] = win[(qd + j) * LZ_BLOCK];
+      }
+      if (go)
+      {
+        cm[4] = r32 == 128u ? m : cm[4];
+        cm[3] = r32 == 96u ? m : cm[3];
+        cm[2] = r32 == 64u ? m : cm[2];
+        cm[1] = r32 == 32u ? m : cm[1];
+        cm[0] = r32 == 0u ? m : cm[0];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < LZ_POP; k++)
+      {
+        const uint32_t qs = qb[k] & 3u;
+        uint32_t len = lz_common16(lz_alignbyte(e[k][1], e[k][0], qs), lz_alignbyte(e[k][2], e[k][1], qs), lz_alignbyte(e[k][3], e[k][2], qs),
+                                   lz_alignbyte(e[k][4], e[k][3], qs), T0, T1, T2, T3);
+        if (len == 16u && ((has >> k) & 1u) != 0)
+          while (len < lim && LZ_WIN8(qb[k] + len) == LZ_WIN8(rel + len))
+            len++;
+        len = len < lim ? len : lim;
+        if (((has >> k) & 1u) != 0 && len > best)
         {
-          has |= m != 0 ? 1u << k : 0u;
-          const uint32_t bit = 31u - clz32(m | 1u);
-          m &= ~(1u << bit);
-          qb[k] = 4u * wd0 + 32u * (uint32_t)r + bit; // window byte index of the candidate (a valid address also when there is none)
-          const uint32_t qd = qb[k] >> 2;
-#pragma unroll
-          for (uint32_t j = 0; j < 5; j++)
-            e[k][j] = win[(qd + j) * LZ_BLOCK];
-        }
-        cm[r] = best < lim ? m : cm[r];
-#pragma unroll
-        for (uint32_t k = 0; k < LZ_POP; k++)
-        {
-          const uint32_t qs = qb[k] & 3u;
-          uint32_t len = lz_common16(lz_alignbyte(e[k][1], e[k][0], qs), lz_alignbyte(e[k][2], e[k][1], qs), lz_alignbyte(e[k][3], e[k][2], qs),
-                                     lz_alignbyte(e[k][4], e[k][3], qs), T0, T1, T2, T3);
-          if (len == 16u && ((has >> k) & 1u) != 0)
-            while (len < lim && LZ_WIN8(qb[k] + len) == LZ_WIN8(rel + len))
-              len++;
-          len = len < lim ? len : lim;
-          if (((has >> k) & 1u) != 0 && len > best)
-          {
-            best = len;
-            besto = rel - qb[k];
-          }
+          best = len;
+          besto = rel - qb[k];
         }
       }
     }
     DG_STAMP(2);
+    // ---- the step is complete when no candidate is left, or the match cannot get longer ----
+    const bool complete = verifying && (best >= lim || (cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) == 0u);
     // a match that ran into the end of the window before the reference's own limit: reload around P and do the step again
-    const bool again = search && best >= lim && lim < maxlen;
+    const bool again = complete && search && best >= lim && lim < maxlen;
     if (again)
       reload = true;
-    const bool emit = active && !again;
-
-    if (emit)
+    if (complete && !again)
     {
       tok[(wr % LZ_TOK_RING) * LZ_BLOCK] = (best << 16) | (besto << 8) | (T0 & 0xFFu);
       wr++;
       P += best >= 3u ? best : 1u;
     }
+    verifying = verifying && !complete;
     peer_store(pub_mine, (wr & 0xFFFFu) | ((P >= n_eff || stop) ? LZ_PUB_DONE : 0u));
     DG_STAMP(3);
   }
