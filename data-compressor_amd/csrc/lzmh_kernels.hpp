@@ -246,11 +246,13 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
     }
     DG_STAMP(7);
 
-    // ---- window: every lane that begins a step reloads [P-128 (rounded down to 16), +432) when one of them needs it ----
+    // ---- window: when a lane that begins a step needs it, every lane with work reloads [P-128 (rounded down to 16), +432).
+    //      A lane in the middle of a step takes part as well -- its candidates all lie in the last 132 bytes before P,
+    //      which the new window holds too; only their window-relative indices move with the base (a multiple of 16) ----
     if (wave_any(start && (reload || (int32_t)(P + LZ_AHEAD) - base > (int32_t)LZ_WIN_BYTES)))
     {
       DG_STAMP(0);
-      if (start)
+      if (start || (todo && verifying))
       {
         base = (int32_t)((P - LZ_HISTORY) & ~15u);
 #pragma unroll
@@ -269,7 +271,12 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
           win[(4u * k + 2u) * LZ_BLOCK] = v2;
           win[(4u * k + 3u) * LZ_BLOCK] = v3;
         }
-        reload = false; // (a lane that does not begin a step in this pass keeps its request)
+        if (verifying)
+        {
+          rel = (uint32_t)((int32_t)P - base);
+          wd0 = (rel - LZ_HISTORY) >> 2; // (lim stays: lengths measured so far were cut at it)
+        }
+        reload = false; // (a lane that waits for ring room keeps its request)
       }
       DG_STAMP(6);
     }
