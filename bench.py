@@ -32,10 +32,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 # The model behind roofline.issue_bound_ms: VALU instructions of the unrolled symbol step (ISA count of the
-# shipped kernel, csrc/Makefile `asm`), cycles per wave instruction on a SIMD that holds one wave
-# (profiles/r01_ubench_issue_cost.txt) and the shader clock under this load.
-ISSUE_INSTR_PER_SYMBOL = 27.5  # 24 per symbol + (10 dump + 18 hand-over) per 8 symbols
-ISSUE_CYCLES_PER_INSTR = 4.3
+# shipped kernel, csrc/Makefile `asm`), cycles per wave instruction of a SIMD (profiles/r01_ubench_issue_cost.txt) and the
+# shader clock under this load.
+ISSUE_INSTR_PER_SYMBOL = 26.7  # 853 VALU instructions per 32-symbol word: 23.5 per symbol + (dump + hand-over) per 8 symbols
+ISSUE_CYCLES_PER_INSTR = 4.0   # a SIMD issues one wave64 VALU instruction per 4 cycles (two waves resident: coding + filling)
 SHADER_CLOCK_HZ = 2.25e9
 
 
@@ -332,12 +332,13 @@ def run_dega(env, args):
             xs = x[:, :n].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(xs, out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
             res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-            # what the kernel really runs against: every channel is a serial chain of coded symbols, one wave per SIMD
-            # issues one instruction per ~4.3 cycles, so a launch cannot finish before the longest chain has been issued
+            # what the kernel really runs against: every channel is a serial chain of coded symbols, 64 Ki channels are one
+            # coding wave per SIMD, and a SIMD issues one instruction of it per 4 cycles: a launch cannot finish before the
+            # longest chain has been issued
             sym = seg_symbols_per_sample(xs)
             issue_ms = T * sym * ISSUE_INSTR_PER_SYMBOL * ISSUE_CYCLES_PER_INSTR / SHADER_CLOCK_HZ * 1e3
             res["roofline"].update({"issue_bound_ms": round(issue_ms, 2), "issue_bound_frac": round(issue_ms / kernel_ms, 4) if kernel_ms > 0 else None,
-                                    "issue_bound_model": "%d samples x %.2f coded symbols x %.1f VALU instructions x %.1f cycles / %.2f GHz, one wave per SIMD"
+                                    "issue_bound_model": "%d samples x %.2f coded symbols x %.1f VALU instructions x %.1f cycles / %.2f GHz, one coding wave per SIMD"
                                                          % (T, sym, ISSUE_INSTR_PER_SYMBOL, ISSUE_CYCLES_PER_INSTR, SHADER_CLOCK_HZ / 1e9)})
             if env.pool is not None:
                 res["cpu_all_cores"] = cpu_all_cores(env.pool, env.ncores, xs)
