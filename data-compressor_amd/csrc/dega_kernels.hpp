@@ -1,18 +1,19 @@
 // dega_kernels.hpp -- the HIP kernels of the DEGA path for gfx950 (MI355X).
 //
-// Mapping: one lane = one meter channel, one wave = 64 adjacent channels, one workgroup = 4 waves (one per SIMD of a
-// CU) sharing the 128 KiB division table in LDS.  Samples are [T][ld] (time-major), so a wave's row read is one
-// coalesced 256-byte segment and every input byte is fetched exactly once.
+// Mapping: one lane = one meter channel, one wave = 64 adjacent channels; a workgroup = 4 (or 8) PAIRS of waves sharing
+// the 64 KiB table of division magics in LDS -- of each pair one wave does the serial arithmetic, its partner on the same
+// SIMD the work around it (see the encode and decode kernels).  Samples are [T][ld] (time-major), so a wave's row read is
+// one coalesced 256-byte segment and every input byte is fetched exactly once.
 //
 // Encode (diff -> seg -> bac fused, nothing but the final stream ever goes back to HBM):
-//   phase F ("fill", row lockstep)   every lane takes the same rows t..t+3, forms the delta, its signed exp-Golomb
-//                                    codeword and appends it to its private bit queue; finished 32-bit words go to the
-//                                    lane's column of an LDS ring.
-//   phase C ("code", word lockstep)  every lane that has a whole word queued takes it and codes its 32 bits with the
-//                                    adaptive binary arithmetic coder -- 32 unrolled, divergence-free symbol steps.
-// Channels need different numbers of coded bits per row; the ring decouples the two lockstep domains, so the wave
-// makes exactly max-over-lanes(words) phase-C steps: the slowest channel of a wave sets its time, as it must
-// (the coder is serial per channel), and nothing is wasted on codeword-length divergence inside a row.
+//   filling wave (row lockstep)   every lane takes the same rows t..t+7, forms the delta, its signed exp-Golomb codeword
+//                                 and appends it to its private bit queue; finished 32-bit words go to the lane's column
+//                                 of an LDS ring.
+//   coding wave (word lockstep)   every lane that has a whole word queued takes it and codes its 32 bits with the
+//                                 adaptive binary arithmetic coder -- 32 unrolled, divergence-free symbol steps.
+// Channels need different numbers of coded bits per row; the ring decouples the two lockstep domains, so the coding wave
+// makes exactly max-over-lanes(words) steps: the slowest channel of a wave sets its time, as it must (the coder is serial
+// per channel), and nothing is wasted on codeword-length divergence inside a row.
 //
 // This header is compiled by hipcc (dega_hip.hip) and, for offline debugging only, by g++ under tests/sim/.
 #pragma once
@@ -115,6 +116,10 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 // F32IN: the rows are float32 readings; Normalize (normalize.c:16-24) runs on each value as it leaves LDS, in front of
 // the difference -- one launch, no int32 intermediate in HBM.  With W64 the rows stay one dword per lane (floats) and
 // the normalized value is 64 bits wide (valuesize 33..64, normalize.c:21-24 with io_int_t = int64).
+// How the two waves of a pair share their SIMD: how long a wave with nothing to do sleeps (units of 64 cycles) and the
+// issue priority of the coding waves.  Compile-time, so that tools/tunebench.py can time variants side by side; measured
+// on the probe batch: priority 3 for the encoder's coding wave -10 %, no effect in the decoder (its pair is bound by the
+// sum of both waves' instructions), sleeps of 2 .. 16 no effect, 32 and more slower.
 #ifndef DG_ENC_FILL_SLEEP
 #define DG_ENC_FILL_SLEEP 2
 #endif
