@@ -36,7 +36,7 @@ struct dega_hip_ctx
   bool profile;
   std::vector<hipEvent_t> ev[4]; // start/stop pairs per kernel kind (0 encode, 1 decode, 2 lzmh encode, 3 lzmh decode)
   std::vector<hipEvent_t> ev_pool; // events handed back by profile_read, reused by the next timed launches
-  int force_waves; // 0 = choose by batch size; 4 / 8 = DEGA_WAVES_PER_WORKGROUP (measurement knob)
+  int force_waves; // 0 = choose by batch size; 4 / 8 = pairs of waves per workgroup, DEGA_WAVES_PER_WORKGROUP (measurement knob)
   Pipeline *pipe;  // streams and buffers of the host-pointer entry points, created on first use
 };
 

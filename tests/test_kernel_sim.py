@@ -119,7 +119,7 @@ def test_decode_kernel_logic_on_golden_sets(sim):
 
 
 def test_wide_workgroup_shape_on_golden_sets(sim):
-    """The 8-wave workgroups (4-row fills, 16/24-word rings) the library uses for batches of more than 64 Ki channels,
+    """The wide workgroups (8 pairs of waves, 4-row fills, 16/24-word rings) the library uses for batches of more than 64 Ki channels,
     forced on the small golden batches: same streams, same samples back."""
     sig_e = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     sig_d = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]

@@ -253,7 +253,7 @@ def test_gpu_stream_ending_after_a_delimiter():
 
 @pytest.mark.gpu
 def test_gpu_valuesize_large_batch_wide_workgroups():
-    """More than 64 Ki channels take the 8-wave workgroup shape; with a narrow value size that is its own instantiation
+    """More than 64 Ki channels take the wide workgroup shape (8 pairs of waves); with a narrow value size that is its own instantiation
     of both kernels.  A sample of channels against the oracle's chain, all of them through the round trip."""
     import torch
     from __graft_entry__ import load_package

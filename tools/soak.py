@@ -15,7 +15,7 @@ from test_valuesize import pack_be, unpack_be  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"  # batches of more than 64 Ki channels: the 8-wave workgroup shapes
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"  # batches of more than 64 Ki channels: the wide workgroup shapes (8 pairs of waves)
 dca = load_package()
 ctx = dca.Context(0)
 t_end = time.time() + budget

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""4-wave vs 8-wave workgroups of the DEGA kernels on one batch: tools/wgbench.py C T  (runs itself once per shape)."""
+"""4 vs 8 pairs of waves per workgroup (DEGA_WAVES_PER_WORKGROUP=4|8) of the DEGA kernels on one batch: tools/wgbench.py C T  (runs itself once per shape)."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
