@@ -117,6 +117,16 @@ DG_DEV uint32_t lz_common16(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, 
   return r;
 }
 
+// the same for 8-byte strings (2 dwords), 0..8
+DG_DEV uint32_t lz_common8(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1)
+{
+  const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+  uint32_t r = 8u;
+  r = x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : r;
+  r = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : r;
+  return r;
+}
+
 // the static prefix code of list position p < 19 (lzmh.c:86-106): returns the code, its length in len
 DG_DEV uint32_t lz_list_code(uint32_t p, uint32_t &len)
 {
@@ -344,16 +354,15 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
 
     DG_STAMP(1);
     // ---- phase 2, one pass: up to LZ_POP candidates of the nearest mask register that still has some, nearest first, every
-    // one measured against the 16 input bytes held in registers (5 window dwords each, all reads of the pass in flight
-    // together: one LDS latency); `len > best` in that order keeps the nearest of equals, like the reference's ascending
-    // scan (:196-214) ----
+    // one measured against the input bytes held in registers (all reads of the pass in flight together: one LDS
+    // latency); `len > best` in that order keeps the nearest of equals, like the reference's ascending scan (:196-214) ----
     if (wave_any(verifying && best < lim && (cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) != 0u))
     {
       const bool go = verifying && best < lim;
       const uint32_t r32 = cm[4] != 0u ? 128u : cm[3] != 0u ? 96u : cm[2] != 0u ? 64u : cm[1] != 0u ? 32u : 0u; // 32 * the register
       uint32_t m = cm[4] != 0u ? cm[4] : cm[3] != 0u ? cm[3] : cm[2] != 0u ? cm[2] : cm[1] != 0u ? cm[1] : cm[0];
       m = go ? m : 0u;
-      uint32_t qb[LZ_POP], e[LZ_POP][5];
+      uint32_t qb[LZ_POP], e[LZ_POP][3];
       uint32_t has = 0;
 #pragma unroll
       for (uint32_t k = 0; k < LZ_POP; k++)
@@ -364,7 +373,7 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
         qb[k] = 4u * wd0 + r32 + bit; // window byte index of the candidate (a valid address also when there is none)
         const uint32_t qd = qb[k] >> 2;
 #pragma unroll
-        for (uint32_t j = 0; j < 5; j++)
+        for (uint32_t j = 0; j < 3; j++)
           e[k][j] = win[(qd + j) * LZ_BLOCK];
       }
       if (go)
@@ -375,19 +384,45 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
         cm[1] = r32 == 32u ? m : cm[1];
         cm[0] = r32 == 0u ? m : cm[0];
       }
+      // first the leading 8 bytes of every candidate (3 window dwords each): all that 97 % of them have to show
+      uint32_t len[LZ_POP];
+      uint32_t longer = 0; // candidates that match all 8 and may go on
 #pragma unroll
       for (uint32_t k = 0; k < LZ_POP; k++)
       {
         const uint32_t qs = qb[k] & 3u;
-        uint32_t len = lz_common16(lz_alignbyte(e[k][1], e[k][0], qs), lz_alignbyte(e[k][2], e[k][1], qs), lz_alignbyte(e[k][3], e[k][2], qs),
-                                   lz_alignbyte(e[k][4], e[k][3], qs), T0, T1, T2, T3);
-        if (len == 16u && ((has >> k) & 1u) != 0)
-          while (len < lim && LZ_WIN8(qb[k] + len) == LZ_WIN8(rel + len))
-            len++;
-        len = len < lim ? len : lim;
-        if (((has >> k) & 1u) != 0 && len > best)
+        len[k] = lz_common8(lz_alignbyte(e[k][1], e[k][0], qs), lz_alignbyte(e[k][2], e[k][1], qs), T0, T1);
+        longer |= (len[k] == 8u && ((has >> k) & 1u) != 0 && lim > 8u) ? 1u << k : 0u;
+      }
+      // then, one candidate per lane and round, the next 8 bytes (and beyond them byte by byte)
+      while (wave_any(longer != 0u))
+      {
+        if (longer != 0u)
         {
-          best = len;
+          const uint32_t k = (uint32_t)__builtin_ctz(longer);
+          longer &= longer - 1u;
+          uint32_t q = qb[0];
+#pragma unroll
+          for (uint32_t i = 1; i < LZ_POP; i++)
+            q = k == i ? qb[i] : q;
+          const uint32_t qd = q >> 2, qs = q & 3u;
+          const uint32_t f2 = win[(qd + 2u) * LZ_BLOCK], f3 = win[(qd + 3u) * LZ_BLOCK], f4 = win[(qd + 4u) * LZ_BLOCK];
+          uint32_t l = 8u + lz_common8(lz_alignbyte(f3, f2, qs), lz_alignbyte(f4, f3, qs), T2, T3);
+          if (l == 16u)
+            while (l < lim && LZ_WIN8(q + l) == LZ_WIN8(rel + l))
+              l++;
+#pragma unroll
+          for (uint32_t i = 0; i < LZ_POP; i++)
+            len[i] = k == i ? l : len[i];
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < LZ_POP; k++)
+      {
+        const uint32_t l = len[k] < lim ? len[k] : lim;
+        if (((has >> k) & 1u) != 0 && l > best)
+        {
+          best = l;
           besto = rel - qb[k];
         }
       }
