@@ -289,7 +289,7 @@ static void encode_launch(bool wide, size_t C, hipStream_t s, const EncodeArgs &
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
 static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_t batch_C, uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err,
-                         hipStream_t s)
+                         hipStream_t s, const uint32_t *rows_ready = nullptr)
 {
   int ret;
   if ((ret = check_job_shape(ctx, j, cap)) != DEGA_OK)
@@ -311,6 +311,7 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
   a.valuesize = (uint32_t)vs;
   a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
   a.factor = j.factor;
+  a.rows_ready = rows_ready;
   // the bounds of normalize.c:21, rounded to float by the host compiler exactly as the reference's are
   a.lo = -(float)((uint64_t)1 << (vs - 1));
   a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);

@@ -214,6 +214,16 @@ DG_DEV uint32_t peer_load(const uint32_t *lds_word)
   return v;
 #endif
 }
+// A word in device memory that the HOST side (a copy engine, on another stream) writes while the kernel runs: read it
+// past every cache (system scope, acquire).
+DG_DEV uint32_t load_written_by_host(const uint32_t *global_word)
+{
+#if defined(DEGA_SIM)
+  return __atomic_load_n(global_word, __ATOMIC_ACQUIRE);
+#else
+  return __hip_atomic_load(global_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
 // nothing to do until the partner has moved: leave the SIMD's issue slots to it for about 64 * n cycles
 template <int N>
 DG_DEV void wave_sleep()

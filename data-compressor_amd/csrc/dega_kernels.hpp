@@ -82,6 +82,9 @@ struct EncodeArgs
   uint32_t big_endian;       // 32-bit samples arrive byte swapped (the big-endian words `encode normalize` writes, bit_file_buffer.c:297-308)
   // F32IN variants (normalize fused into the fill phase, normalize.c:9-27): x holds raw float32 bits
   float factor, lo, hi;      // normalization factor; range of normalize.c:21 for the value size, rounded to float by the host compiler
+  // NULL: every row of x is there when the kernel starts.  Else: rows [0, *rows_ready) are -- the host pipeline uploads a
+  // batch of few, long channels in bands of rows while the kernel already codes (the word grows; dega_pipeline.hpp)
+  const uint32_t *rows_ready;
 };
 
 // `symbols`: no channel of the batch codes more symbols than this (cum[0] starts at 3 and grows by one per symbol until
@@ -108,7 +111,7 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 // it still waits for, the filling wave's instructions go into.  The two talk through one published word per lane and
 // direction (counters modulo 2^16, peer_store / peer_load); a wave with nothing to do sleeps.
 //   filler publishes: ring words written (mod 2^16) | bits of the final, partial word << 16 | all rows done << 24 |
-//                     a value was out of range << 25
+//                     a value was out of range << 25 | the rows stopped arriving (rows_ready) << 26
 //   coder publishes:  ring words consumed (mod 2^16)
 // ROWS rows per fill batch, RING / ORING words of seg-bit / output ring per lane.
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
@@ -141,7 +144,8 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 constexpr uint32_t ENC_PAIRS = 4;
 constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
 constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
-constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25;
+constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25, ENC_PUB_LOST = 1u << 26;
+constexpr uint32_t ENC_ROWS_POLLS = 1u << 25; // polls of rows_ready (about half a microsecond each) before a wave gives the upload up
 
 // ---- the filling wave ------------------------------------------------------------------------------------------------
 template <bool NARROW, uint32_t ROWS, uint32_t RING, bool W64, bool F32IN>
@@ -211,10 +215,32 @@ DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_
       rowp += a.ld;
     }
   };
+  // rows that are in device memory (all of them unless the host pipeline is still uploading: EncodeArgs::rows_ready)
+  uint32_t rows_there = a.rows_ready == nullptr ? 0xFFFFFFFFu : 0u;
+  bool lost = false;
+  auto await_rows = [&](size_t upto) // rows [0, min(upto, T)) are there; false: given up
+  {
+    const uint32_t want = (uint32_t)(upto < a.T ? upto : a.T);
+    for (uint32_t polls = 0; rows_there < want; polls++)
+    {
+      rows_there = wave_uniform(load_written_by_host(a.rows_ready));
+      if (rows_there >= want)
+        break;
+      if (polls >= ENC_ROWS_POLLS)
+        return false;
+      wave_sleep<16>();
+    }
+    return true;
+  };
   if (a.T > 0)
-    issue_rows(0);
+  {
+    if (await_rows(ROWS))
+      issue_rows(0);
+    else
+      lost = true;
+  }
 
-  while (t < a.T)
+  while (t < a.T && !lost)
   {
     // ---- the same ROWS rows for every lane, as soon as every lane's ring has room for what they may add ---------------
     const uint32_t taken = peer_load(pub_peer);
@@ -331,14 +357,19 @@ DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_
       }
     }
     t += left < ROWS ? left : ROWS;
-    if (t < a.T)
-      issue_rows(t); // in flight while the coder works through this batch
     peer_store(pub_mine, q.wr & 0xFFFFu);
+    if (t < a.T)
+    {
+      if (await_rows(t + ROWS))
+        issue_rows(t); // in flight while the coder works through this batch
+      else
+        lost = true;
+    }
   }
   // the last, partial word of the seg stream goes into the next ring slot, left aligned (the slot is free: a batch's
   // worst case counts it)
   ring_col[(q.wr % RING) * 64u] = q.cnt != 0u ? (uint32_t)(q.acc << (32u - q.cnt)) : 0u;
-  peer_store(pub_mine, (q.wr & 0xFFFFu) | (q.cnt << 16) | ENC_PUB_DONE | (lane_err != OK ? ENC_PUB_BAD : 0u));
+  peer_store(pub_mine, (q.wr & 0xFFFFu) | (q.cnt << 16) | ENC_PUB_DONE | (lane_err != OK ? ENC_PUB_BAD : 0u) | (lost ? ENC_PUB_LOST : 0u));
 }
 
 // ---- the coding wave -------------------------------------------------------------------------------------------------
@@ -516,7 +547,7 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     for (uint32_t i = 0; i < tail; i++)
       enc.encode_bit((tword >> (31u - i)) & 1u, tab);
     a.out_bits[c] = enc.finish(tab);
-    a.err[c] = (peer & ENC_PUB_BAD) != 0u ? ERR_INVALID_VALUE : enc.err;
+    a.err[c] = (peer & ENC_PUB_LOST) != 0u ? ERR_LIBRARY_CALL : (peer & ENC_PUB_BAD) != 0u ? ERR_INVALID_VALUE : enc.err;
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
     if (lane < 8)
       a.out_bits[c] = stamp_sum[lane];

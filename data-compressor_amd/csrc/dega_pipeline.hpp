@@ -378,6 +378,12 @@ struct Slot
   GrowDev a, b, meta; // encode: a = samples, then the packed streams; b = slabs.  decode: a = packed streams, b = slabs, c = samples
   GrowDev c;
   GrowPin hmeta, stage;
+  // uploads in bands of rows beside the running kernel (encode of few, long channels): the copies' stream, the event that
+  // orders them behind the reset of the progress word, the word itself and the values it takes
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev = nullptr;
+  GrowDev progress;
+  GrowPin progress_values;
 };
 
 constexpr int MAX_SLOTS = 16;
@@ -436,6 +442,12 @@ static void pipeline_destroy(Pipeline *p)
   {
     if (sl.s != nullptr)
       (void)hipStreamDestroy(sl.s);
+    if (sl.s2 != nullptr)
+      (void)hipStreamDestroy(sl.s2);
+    if (sl.ev != nullptr)
+      (void)hipEventDestroy(sl.ev);
+    sl.progress.release();
+    sl.progress_values.release();
     sl.a.release();
     sl.b.release();
     sl.c.release();
@@ -519,6 +531,25 @@ static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes
   if (want_all_resident && (size_t)p.nslots < p.nchunks)
     p.nslots = -1; // the caller has to split the batch
   return p;
+}
+
+// Rows per upload band when the samples of a chunk go up beside its running kernel (0: upload first, the usual way).
+// Only worth it when there are too few chunks to overlap one chunk's copy with another's kernel and the channels are long;
+// bands end on multiples of 32 rows, so that no 128-byte line of the device array holds rows of two bands (a line read
+// with the last rows of one band must not carry stale bytes of the next), and are about 32 MiB each.
+static size_t band_rows_of(const ChunkPlan &plan, const Shape &j, size_t row_bytes)
+{
+  size_t band_bytes = (size_t)32 << 20, min_T = 4096;
+  if (const char *e = getenv("DEGA_PIPELINE_BAND_BYTES")) // measurement / test knob: 0 = no bands, else the size of a band
+  {
+    band_bytes = (size_t)strtoull(e, nullptr, 10);
+    min_T = 64;
+  }
+  if (band_bytes == 0 || plan.nchunks > 2 || j.T < min_T || row_bytes == 0)
+    return 0;
+  size_t rows = std::max<size_t>(band_bytes / row_bytes, 32);
+  rows = (rows + 31) / 32 * 32;
+  return rows >= j.T ? 0 : rows;
 }
 
 // ---- encode ------------------------------------------------------------------------------------------------------------
@@ -630,13 +661,47 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     HIP_TRY(ctx, sl.b.need(ch.n * cap + 64), DEGA_ERROR_MEMORY);
     HIP_TRY(ctx, sl.meta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
     HIP_TRY(ctx, sl.hmeta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
-    HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, (const uint8_t *)samples + ch.c0 * esz, j.ld * esz, ch.n * esz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
     MetaView dm(sl.meta.p, ch.n);
     Shape cj = j;
     cj.C = ch.n;
     cj.ld = ch.n;
-    if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s)) != DEGA_OK)
-      return r;
+    const uint8_t *const src = (const uint8_t *)samples + ch.c0 * esz;
+    const size_t band_rows = band_rows_of(plan, j, ch.n * esz);
+    if (band_rows == 0)
+    {
+      HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, src, j.ld * esz, ch.n * esz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
+      if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s)) != DEGA_OK)
+        return r;
+    }
+    else
+    {
+      // Few, long channels: a channel's serial chain takes the same kernel time however few channels there are, so
+      // upload and kernel of the (only) chunk must not take turns.  The kernel starts at once and its filling waves take
+      // rows as they arrive: the rows go up in bands on a second stream, each followed by the new value of the progress
+      // word the kernel polls (EncodeArgs::rows_ready).
+      if (sl.s2 == nullptr)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.s2, hipStreamNonBlocking), DEGA_ERROR_LIBRARY_CALL);
+      if (sl.ev == nullptr)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming), DEGA_ERROR_LIBRARY_CALL);
+      const size_t nbands = (j.T + band_rows - 1) / band_rows;
+      HIP_TRY(ctx, sl.progress.need(256), DEGA_ERROR_MEMORY);
+      HIP_TRY(ctx, sl.progress_values.need(sizeof(uint32_t) * nbands), DEGA_ERROR_MEMORY);
+      HIP_TRY(ctx, hipMemsetAsync(sl.progress.p, 0, sizeof(uint32_t), sl.s), DEGA_ERROR_LIBRARY_CALL);
+      HIP_TRY(ctx, hipEventRecord(sl.ev, sl.s), DEGA_ERROR_LIBRARY_CALL);
+      if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s, (const uint32_t *)sl.progress.p)) != DEGA_OK)
+        return r;
+      HIP_TRY(ctx, hipStreamWaitEvent(sl.s2, sl.ev, 0), DEGA_ERROR_LIBRARY_CALL);
+      uint32_t *const values = (uint32_t *)sl.progress_values.p;
+      for (size_t b = 0; b < nbands; b++)
+      {
+        const size_t t0 = b * band_rows, t1 = std::min(j.T, t0 + band_rows);
+        HIP_TRY(ctx, rows_to_device(pl, sl.s2, (uint8_t *)sl.a.p + t0 * ch.n * esz, src + t0 * j.ld * esz, j.ld * esz, ch.n * esz, t1 - t0, samples_pinned),
+                DEGA_ERROR_LIBRARY_CALL);
+        values[b] = (uint32_t)t1;
+        HIP_TRY(ctx, hipMemcpyAsync(sl.progress.p, &values[b], sizeof(uint32_t), hipMemcpyHostToDevice, sl.s2), DEGA_ERROR_LIBRARY_CALL);
+      }
+      TRACE("chunk %zu: %zu bands of %zu rows beside the kernel", k, nbands, band_rows);
+    }
     hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
     HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
     HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, MetaView::bytes(ch.n), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
@@ -650,6 +715,8 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     Slot &sl = pl->slot[ch.slot];
     TRACE("chunk %zu stage2 wait", k);
     HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
+    if (sl.s2 != nullptr)
+      HIP_TRY(ctx, hipStreamSynchronize(sl.s2), DEGA_ERROR_LIBRARY_CALL); // (long done: the kernel has coded the last band)
     TRACE("chunk %zu sizes on the host", k);
     MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
     bool too_small = false;

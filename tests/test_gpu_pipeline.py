@@ -150,6 +150,32 @@ def test_pipeline_chunks_and_streams_equal_device_resident(dca, ctx):
     assert ret == dca.ERROR_MEMORY and int(o2[Cn]) == packed.size and (b2 == hbits).all() and (e2 == 0).all()
 
 
+def test_rows_uploaded_in_bands_beside_the_running_kernel(dca, ctx, monkeypatch):
+    """Few, long channels: the kernel starts before the samples are there and takes the rows as the bands of the upload
+    arrive (EncodeArgs::rows_ready).  Forced onto small batches with small bands -- many band ends, a ragged last wave,
+    pageable and pinned sources, a float batch -- and compared with the device-resident kernel's streams."""
+    import torch
+    monkeypatch.setenv("DEGA_PIPELINE_BAND_BYTES", "65536")
+    for Cn, T in ((300, 5000), (64, 9001), (1030, 700)):
+        x = ctx.synth(Cn, T, seed=7 + Cn, S=120)
+        out, bits, err = ctx.encode(x, adaptive=1, cap=4 * T + 64)
+        dpacked, doff = ctx.compact(out, bits)
+        torch.cuda.synchronize()
+        xh = x.cpu().numpy()
+        packed, offsets, hbits, herr = ctx.encode_job(xh, adaptive=1)
+        assert (herr == 0).all() and (hbits.astype(np.int64) == bits.cpu().numpy()).all(), (Cn, T)
+        assert packed.tobytes() == dpacked.cpu().numpy().tobytes(), (Cn, T)
+        pin = dca.PinnedArray((T, Cn), np.int32)
+        pin.array[:] = xh
+        p2, o2, b2, e2 = ctx.encode_job(pin.array, adaptive=1)
+        assert (e2 == 0).all() and p2.tobytes() == packed.tobytes(), (Cn, T)
+    v = (np.cumsum(np.random.default_rng(3).normal(0, 0.4, (6000, 130)), axis=0) + 230.0).astype(np.float32)
+    pf, of, bf, ef = ctx.encode_job(v, adaptive=1, samples=dca.SAMPLES_F32, factor=100.0)
+    monkeypatch.setenv("DEGA_PIPELINE_BAND_BYTES", "0")
+    pg, og, bg, eg = ctx.encode_job(v, adaptive=1, samples=dca.SAMPLES_F32, factor=100.0)
+    assert (ef == 0).all() and (bf == bg).all() and pf.tobytes() == pg.tobytes()
+
+
 def test_streams_longer_than_their_samples_take_the_worst_case_pass(dca, ctx):
     """Noise: ~60 coded bits per 32-bit sample.  The pipeline's first attempt sizes slabs for streams no longer than their
     samples; chunks that do not fit are redone with worst-case slabs -- same streams as the oracle's, mixed with channels
