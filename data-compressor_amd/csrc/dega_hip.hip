@@ -365,7 +365,7 @@ static void decode_launch(bool wide, size_t C, hipStream_t s, const DecodeArgs &
 }
 
 static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, const Shape &j, size_t batch_C, void *x,
-                         uint64_t *out_count, int32_t *err, hipStream_t s)
+                         uint64_t *out_count, int32_t *err, hipStream_t s, uint32_t *rows_done = nullptr, uint32_t band_rows = 0)
 {
   int ret;
   if ((ret = check_job_shape(ctx, j, cap)) != DEGA_OK)
@@ -388,6 +388,8 @@ static int launch_decode(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const
   a.valuesize = (uint32_t)vs;
   a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
   a.factor = j.factor;
+  a.rows_done = band_rows != 0 ? rows_done : nullptr;
+  a.band_rows = band_rows;
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
   const bool wide = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
   {

@@ -224,6 +224,16 @@ DG_DEV uint32_t load_written_by_host(const uint32_t *global_word)
   return __hip_atomic_load(global_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
+// A word the HOST reads while the kernel runs (pinned host memory): every store of this wave so far is written back and
+// visible to the host side -- a copy engine included -- before the word is (system scope, release).
+DG_DEV void store_read_by_host(uint32_t *host_word, uint32_t v)
+{
+#if defined(DEGA_SIM)
+  __atomic_store_n(host_word, v, __ATOMIC_RELEASE);
+#else
+  __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
 // nothing to do until the partner has moved: leave the SIMD's issue slots to it for about 64 * n cycles
 template <int N>
 DG_DEV void wave_sleep()

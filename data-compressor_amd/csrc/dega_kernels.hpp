@@ -643,6 +643,11 @@ struct DecodeArgs
   uint32_t valuesize;  // 1..32: samples come out as the low valuesize bits, zero extended (diff.c:34)
   uint32_t big_endian; // 32-bit samples are stored byte swapped (what `decode diff` writes: big-endian words)
   float factor;        // F32OUT variants: Denormalize (normalize.c:29-41) fused into the row write; x is float [T][ld]
+  // NULL, or one word per wave of 64 channels in HOST memory: the rows the wave has stored, reported whenever it passes a
+  // multiple of band_rows (all ones when it is done) -- the host pipeline downloads a batch of few, long channels in bands
+  // of rows while the kernel is still decoding (dega_pipeline.hpp)
+  uint32_t *rows_done;
+  uint32_t band_rows;
 };
 
 struct alignas(16) DecodeQuad
@@ -904,6 +909,8 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   if (!wave_any(live))
     return; // a wave past the last channel
   uint32_t peer = peer_load(pub_peer);
+  uint32_t *const report = a.rows_done != nullptr ? a.rows_done + c_wave0 / 64u : nullptr; // (wave uniform)
+  uint32_t next_report = a.band_rows;
 
   // one decoded value -> memory, in the form the variant writes (rows past a failed channel's last sample: zeros)
   auto store_value = [&](uint32_t row, uint32_t lo, uint32_t hi, bool valid) {
@@ -1082,11 +1089,19 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
           break;
       }
     }
+    if (report != nullptr && rows_stored >= next_report)
+    {
+      if (lane == 0)
+        store_read_by_host(report, rows_stored);
+      next_report = (rows_stored / a.band_rows + 1u) * a.band_rows;
+    }
     if (wave_all(lane_final) && (rows_stored >= T32 || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
     carry_over = rows_stored != rows_before || wave_any(t_lane != t_before || lane_final != final_before);
   }
   peer_store(pub_mine, (rd & 0xFFFFu) | DEC_PUB_FINAL);
+  if (report != nullptr && lane == 0)
+    store_read_by_host(report, 0xFFFFFFFFu);
   if (live)
   {
     a.err[c] = lane_err;

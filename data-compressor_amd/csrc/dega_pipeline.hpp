@@ -14,6 +14,8 @@
 // known).  No collective, no peer traffic (channels are independent: diff.c:11, bac.c:150).
 #pragma once
 
+#include <sched.h>
+
 struct GrowDev // device buffer that only grows
 {
   void *p = nullptr;
@@ -854,6 +856,7 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
   {
     size_t c0, n;
     int slot;
+    size_t band_rows; // 0: the samples come home after the kernel; else in bands of rows beside it
   };
   std::vector<DecChunk> chunks(plan.nchunks);
   const bool samples_pinned = is_pinned(samples), packed_pinned = is_pinned(packed);
@@ -895,7 +898,21 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
     Shape cj = j;
     cj.C = ch.n;
     cj.ld = ch.n;
-    if ((r = launch_decode(ctx, (const uint8_t *)sl.b.p, cap, dm.bits, cj, j.C, sl.c.p, out_count != nullptr ? dm.counts : nullptr, dm.err, sl.s)) != DEGA_OK)
+    // few, long channels (see encode_share): the rows go home in bands while the kernel is still decoding; every wave of 64
+    // channels reports the rows it has stored in a word of pinned host memory
+    ch.band_rows = out_count == nullptr ? band_rows_of(plan, j, ch.n * osz) : 0;
+    uint32_t *reports = nullptr;
+    if (ch.band_rows != 0)
+    {
+      const size_t waves = (ch.n + 63) / 64;
+      HIP_TRY(ctx, sl.progress_values.need(sizeof(uint32_t) * waves), DEGA_ERROR_MEMORY);
+      reports = (uint32_t *)sl.progress_values.p;
+      memset(reports, 0, sizeof(uint32_t) * waves);
+      if (sl.s2 == nullptr)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.s2, hipStreamNonBlocking), DEGA_ERROR_LIBRARY_CALL);
+    }
+    if ((r = launch_decode(ctx, (const uint8_t *)sl.b.p, cap, dm.bits, cj, j.C, sl.c.p, out_count != nullptr ? dm.counts : nullptr, dm.err, sl.s, reports,
+                           (uint32_t)ch.band_rows)) != DEGA_OK)
       return r;
     // counts and err come back right behind the kernel
     HIP_TRY(ctx, hipMemcpyAsync(hm.counts, dm.counts, ch.n * sizeof(uint64_t) + ch.n * sizeof(int32_t), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
@@ -905,7 +922,37 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
   auto stage2 = [&](size_t k) -> int {
     DecChunk &ch = chunks[k];
     Slot &sl = pl->slot[ch.slot];
-    HIP_TRY(ctx, rows_to_host(pl, sl.s, (uint8_t *)samples + ch.c0 * osz, j.ld * osz, sl.c.p, ch.n * osz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
+    if (ch.band_rows == 0)
+      HIP_TRY(ctx, rows_to_host(pl, sl.s, (uint8_t *)samples + ch.c0 * osz, j.ld * osz, sl.c.p, ch.n * osz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
+    else
+    {
+      const volatile uint32_t *const reports = (const volatile uint32_t *)sl.progress_values.p;
+      const size_t waves = (ch.n + 63) / 64;
+      bool kernel_over = false;
+      for (size_t t0 = 0; t0 < j.T; t0 += ch.band_rows)
+      {
+        const size_t t1 = std::min(j.T, t0 + ch.band_rows);
+        for (;;) // until every wave has stored the band's rows (or the kernel is over: then they are all there)
+        {
+          uint32_t least = 0xFFFFFFFFu;
+          for (size_t w = 0; w < waves; w++)
+          {
+            const uint32_t v = reports[w];
+            least = v < least ? v : least;
+          }
+          if (least >= t1 || kernel_over)
+            break;
+          if (hipStreamQuery(sl.s) != hipErrorNotReady)
+            kernel_over = true;
+          else
+            sched_yield();
+        }
+        HIP_TRY(ctx, rows_to_host(pl, sl.s2, (uint8_t *)samples + (t0 * j.ld + ch.c0) * osz, j.ld * osz, (const uint8_t *)sl.c.p + t0 * ch.n * osz, ch.n * osz,
+                                  t1 - t0, samples_pinned),
+                DEGA_ERROR_LIBRARY_CALL);
+      }
+      HIP_TRY(ctx, hipStreamSynchronize(sl.s2), DEGA_ERROR_LIBRARY_CALL);
+    }
     HIP_TRY(ctx, pl->stager.drain(), DEGA_ERROR_LIBRARY_CALL); // the slot's buffers are free for its next chunk only after this
     HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
     MetaView hm(sl.hmeta.p, ch.n);

@@ -151,9 +151,10 @@ def test_pipeline_chunks_and_streams_equal_device_resident(dca, ctx):
 
 
 def test_rows_uploaded_in_bands_beside_the_running_kernel(dca, ctx, monkeypatch):
-    """Few, long channels: the kernel starts before the samples are there and takes the rows as the bands of the upload
-    arrive (EncodeArgs::rows_ready).  Forced onto small batches with small bands -- many band ends, a ragged last wave,
-    pageable and pinned sources, a float batch -- and compared with the device-resident kernel's streams."""
+    """Few, long channels: the encode kernel starts before the samples are there and takes the rows as the bands of the
+    upload arrive (EncodeArgs::rows_ready); the decode kernel's rows go home in bands while it is still running
+    (DecodeArgs::rows_done).  Forced onto small batches with small bands -- many band ends, a ragged last wave, pageable and
+    pinned memory, a float batch -- and compared with the device-resident kernel's streams / the input."""
     import torch
     monkeypatch.setenv("DEGA_PIPELINE_BAND_BYTES", "65536")
     for Cn, T in ((300, 5000), (64, 9001), (1030, 700)):
@@ -169,6 +170,12 @@ def test_rows_uploaded_in_bands_beside_the_running_kernel(dca, ctx, monkeypatch)
         pin.array[:] = xh
         p2, o2, b2, e2 = ctx.encode_job(pin.array, adaptive=1)
         assert (e2 == 0).all() and p2.tobytes() == packed.tobytes(), (Cn, T)
+        # and back: the rows come home in bands while the decode kernel is still running (DecodeArgs::rows_done)
+        back, derr = ctx.decode_job(packed, offsets, hbits, T, adaptive=1)
+        assert (derr == 0).all() and (back == xh).all(), (Cn, T)
+        pin.array[:] = 0
+        back2, derr2 = ctx.decode_job(packed, offsets, hbits, T, adaptive=1, out=pin.array)
+        assert (derr2 == 0).all() and (pin.array == xh).all(), (Cn, T)
     v = (np.cumsum(np.random.default_rng(3).normal(0, 0.4, (6000, 130)), axis=0) + 230.0).astype(np.float32)
     pf, of, bf, ef = ctx.encode_job(v, adaptive=1, samples=dca.SAMPLES_F32, factor=100.0)
     monkeypatch.setenv("DEGA_PIPELINE_BAND_BYTES", "0")
