@@ -145,7 +145,7 @@ constexpr uint32_t ENC_PAIRS = 4;
 constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
 constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
 constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25, ENC_PUB_LOST = 1u << 26;
-constexpr uint32_t ENC_ROWS_POLLS = 1u << 25; // polls of rows_ready (about half a microsecond each) before a wave gives the upload up
+constexpr uint32_t ENC_ROWS_POLLS = 1u << 20; // polls of rows_ready (2 - 3 microseconds each) before a wave gives the upload up
 
 // ---- the filling wave ------------------------------------------------------------------------------------------------
 template <bool NARROW, uint32_t ROWS, uint32_t RING, bool W64, bool F32IN>

@@ -380,10 +380,9 @@ struct Slot
   GrowDev a, b, meta; // encode: a = samples, then the packed streams; b = slabs.  decode: a = packed streams, b = slabs, c = samples
   GrowDev c;
   GrowPin hmeta, stage;
-  // uploads in bands of rows beside the running kernel (encode of few, long channels): the copies' stream, the event that
-  // orders them behind the reset of the progress word, the word itself and the values it takes
+  // uploads / downloads in bands of rows beside the running kernel (few, long channels): the copies' stream, the progress
+  // word of the encode kernel and the values it takes (decode: the waves' progress words, written by the kernel)
   hipStream_t s2 = nullptr;
-  hipEvent_t ev = nullptr;
   GrowDev progress;
   GrowPin progress_values;
 };
@@ -393,6 +392,7 @@ constexpr int MAX_SLOTS = 16;
 struct Pipeline
 {
   Slot slot[MAX_SLOTS];
+  bool bands_broken = false; // an encode kernel once gave up waiting for its rows: no more uploads beside running kernels
   GrowDev redo_slabs, redo_packed, redo_meta;
   GrowPin redo_hmeta;
   Stager stager;
@@ -446,8 +446,6 @@ static void pipeline_destroy(Pipeline *p)
       (void)hipStreamDestroy(sl.s);
     if (sl.s2 != nullptr)
       (void)hipStreamDestroy(sl.s2);
-    if (sl.ev != nullptr)
-      (void)hipEventDestroy(sl.ev);
     sl.progress.release();
     sl.progress_values.release();
     sl.a.release();
@@ -573,6 +571,7 @@ struct EncChunk
   int slot = 0;
   uint64_t total = 0; // packed bytes of the chunk
   bool gathered = false, redone = false;
+  bool bands = false; // its rows went up in bands beside the running kernel
   std::vector<uint8_t> redo_bytes; // a chunk that needed worst-case slabs: its packed streams, already on the host
 };
 
@@ -668,7 +667,7 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     cj.C = ch.n;
     cj.ld = ch.n;
     const uint8_t *const src = (const uint8_t *)samples + ch.c0 * esz;
-    const size_t band_rows = band_rows_of(plan, j, ch.n * esz);
+    const size_t band_rows = pl->bands_broken ? 0 : band_rows_of(plan, j, ch.n * esz);
     if (band_rows == 0)
     {
       HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, src, j.ld * esz, ch.n * esz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
@@ -683,17 +682,17 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
       // word the kernel polls (EncodeArgs::rows_ready).
       if (sl.s2 == nullptr)
         HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.s2, hipStreamNonBlocking), DEGA_ERROR_LIBRARY_CALL);
-      if (sl.ev == nullptr)
-        HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming), DEGA_ERROR_LIBRARY_CALL);
       const size_t nbands = (j.T + band_rows - 1) / band_rows;
       HIP_TRY(ctx, sl.progress.need(256), DEGA_ERROR_MEMORY);
-      HIP_TRY(ctx, sl.progress_values.need(sizeof(uint32_t) * nbands), DEGA_ERROR_MEMORY);
-      HIP_TRY(ctx, hipMemsetAsync(sl.progress.p, 0, sizeof(uint32_t), sl.s), DEGA_ERROR_LIBRARY_CALL);
-      HIP_TRY(ctx, hipEventRecord(sl.ev, sl.s), DEGA_ERROR_LIBRARY_CALL);
+      HIP_TRY(ctx, sl.progress_values.need(sizeof(uint32_t) * (nbands + 1)), DEGA_ERROR_MEMORY);
+      uint32_t *const values = (uint32_t *)sl.progress_values.p;
+      // The word starts at 0 -- written here and now (the slot is idle), not by a command on a stream: the copies' stream
+      // must depend on nothing that is queued behind a kernel, or a hardware queue shared between streams could hold the
+      // copies back behind the very kernel that waits for them.
+      values[nbands] = 0;
+      HIP_TRY(ctx, hipMemcpy(sl.progress.p, &values[nbands], sizeof(uint32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
       if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s, (const uint32_t *)sl.progress.p)) != DEGA_OK)
         return r;
-      HIP_TRY(ctx, hipStreamWaitEvent(sl.s2, sl.ev, 0), DEGA_ERROR_LIBRARY_CALL);
-      uint32_t *const values = (uint32_t *)sl.progress_values.p;
       for (size_t b = 0; b < nbands; b++)
       {
         const size_t t0 = b * band_rows, t1 = std::min(j.T, t0 + band_rows);
@@ -703,6 +702,9 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
         HIP_TRY(ctx, hipMemcpyAsync(sl.progress.p, &values[b], sizeof(uint32_t), hipMemcpyHostToDevice, sl.s2), DEGA_ERROR_LIBRARY_CALL);
       }
       TRACE("chunk %zu: %zu bands of %zu rows beside the kernel", k, nbands, band_rows);
+      ch.bands = true; // (what follows the kernel on its stream is enqueued in stage 2, when the copies are through:
+                       //  nothing waits in a queue behind the kernel while it waits for rows)
+      return DEGA_OK;
     }
     hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
     HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
@@ -716,11 +718,38 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     EncChunk &ch = run.chunks[k];
     Slot &sl = pl->slot[ch.slot];
     TRACE("chunk %zu stage2 wait", k);
-    HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
-    if (sl.s2 != nullptr)
-      HIP_TRY(ctx, hipStreamSynchronize(sl.s2), DEGA_ERROR_LIBRARY_CALL); // (long done: the kernel has coded the last band)
-    TRACE("chunk %zu sizes on the host", k);
     MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
+    if (ch.bands)
+    {
+      HIP_TRY(ctx, hipStreamSynchronize(sl.s2), DEGA_ERROR_LIBRARY_CALL); // every row is on the device
+      hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
+      HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+      HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, MetaView::bytes(ch.n), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
+    if (ch.bands)
+    {
+      // a kernel that stopped seeing rows arrive gives up after a few seconds (ENC_ROWS_POLLS) and says so: the chunk is
+      // done again the plain way, and this context uploads no more batches in bands
+      bool lost = false;
+      for (size_t i = 0; i < ch.n && !lost; i++)
+        lost = hm.err[i] == DEGA_ERROR_LIBRARY_CALL;
+      if (lost)
+      {
+        pl->bands_broken = true;
+        Shape cj = j;
+        cj.C = ch.n;
+        cj.ld = ch.n;
+        int r;
+        if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s)) != DEGA_OK)
+          return r;
+        hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
+        HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+        HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, MetaView::bytes(ch.n), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
+        HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
+      }
+    }
+    TRACE("chunk %zu sizes on the host", k);
     bool too_small = false;
     if (cap < worst_cap(j))
       for (size_t i = 0; i < ch.n && !too_small; i++)
