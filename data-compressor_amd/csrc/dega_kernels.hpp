@@ -912,8 +912,11 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   uint32_t *const report = a.rows_done != nullptr ? a.rows_done + c_wave0 / 64u : nullptr; // (wave uniform)
   uint32_t next_report = a.band_rows;
 
-  // one decoded value -> memory, in the form the variant writes (rows past a failed channel's last sample: zeros)
+  // one decoded value -> memory, in the form the variant writes (rows past a failed channel's last sample: zeros).
+  // `row` is the same in every lane: the row's address is a scalar, the lane adds its column.
+  const bool swap_bytes = a.big_endian != 0;
   auto store_value = [&](uint32_t row, uint32_t lo, uint32_t hi, bool valid) {
+    const size_t at = (size_t)row * a.ld + c_wave0; // (wave uniform)
     if constexpr (F32OUT)
     {
       float v;
@@ -924,12 +927,12 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
       }
       else
         v = denormalize_value((float)(NARROW ? (int32_t)(lo << sp.vshift) >> sp.vshift : (int32_t)lo), a.factor);
-      reinterpret_cast<float *>(a.x)[(size_t)row * a.ld + c] = valid ? v : 0.0f;
+      (reinterpret_cast<float *>(a.x) + at)[lane] = valid ? v : 0.0f;
     }
     else if constexpr (W64)
-      reinterpret_cast<int64_t *>(a.x)[(size_t)row * a.ld + c] = valid ? (int64_t)(((uint64_t)hi << 32) | lo) : 0;
+      (reinterpret_cast<int64_t *>(a.x) + at)[lane] = valid ? (int64_t)(((uint64_t)hi << 32) | lo) : 0;
     else
-      a.x[(size_t)row * a.ld + c] = valid ? (int32_t)(a.big_endian ? bswap32(lo) : lo) : 0;
+      (a.x + at)[lane] = valid ? (int32_t)(swap_bytes ? bswap32(lo) : lo) : 0;
   };
 
   for (;;)
@@ -1042,18 +1045,19 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     // ballot, eight samples out of the ring, eight 256-byte stores.
     while (full_wave && rows_stored + 8u <= T32 && wave_all(t_lane >= rows_stored + 8u))
     {
+      const uint32_t r0 = wave_uniform(rows_stored);
       uint32_t cand[8], cand_hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (uint32_t k = 0; k < 8; k++)
       {
-        cand[k] = sring[((rows_stored + k) % SRING) * 64u];
+        cand[k] = sring[((r0 + k) % SRING) * 64u];
         if constexpr (W64)
-          cand_hi[k] = sring_hi[((rows_stored + k) % SRING) * 64u];
+          cand_hi[k] = sring_hi[((r0 + k) % SRING) * 64u];
       }
 #pragma unroll
       for (uint32_t k = 0; k < 8; k++)
-        store_value(rows_stored + k, cand[k], cand_hi[k], true);
-      rows_stored += 8;
+        store_value(r0 + k, cand[k], cand_hi[k], true);
+      rows_stored = r0 + 8u;
     }
     // The ends -- a partial wave, channels that have finished or failed, the last rows, a reported count (then rows past
     // the longest channel of the wave are not written at all): up to 4 rows per pass, each checked on its own.
@@ -1076,7 +1080,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++)
         {
-          const uint32_t row = rows_stored + k;
+          const uint32_t row = wave_uniform(rows_stored) + k;
           if (wrote == k && row < T32 && (four || wave_all(lane_final || t_lane > row)) && (a.out_count == nullptr || wave_any(t_lane > row)))
           {
             if (live)
