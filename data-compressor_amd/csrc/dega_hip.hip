@@ -687,10 +687,7 @@ extern "C" int dega_hip_lzmh_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, si
   hipStream_t s = (hipStream_t)stream;
   {
     LaunchTimer lt(ctx, 3, s);
-    if (C <= 65536 && ctx->force_waves != 4) // no more waves than SIMDs: half-filled waves, two per SIMD (see the kernel)
-      hipLaunchKernelGGL(lzmh_decode_kernel<32>, dim3((unsigned)((C + 127) / 128)), dim3(LZ_BLOCK), 0, s, a);
-    else
-      hipLaunchKernelGGL(lzmh_decode_kernel<64>, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(lzmh_decode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZD_THREADS), 0, s, a);
   }
   HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;

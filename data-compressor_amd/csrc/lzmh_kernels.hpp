@@ -726,38 +726,39 @@ struct LzmhDecodeArgs
   int32_t *err;            // [C]
 };
 
-// LPW = channels per wave.  The decoder is a chain of dependent LDS round trips (VALUBusy 28 % with one wave per SIMD), so
-// when a batch has no more waves than the GPU has SIMDs (up to 64 Ki channels) it runs with half-filled waves, 32
-// channels each: twice as many waves, two per SIMD (two 68 KiB workgroups fit a CU), and one hides the other's latency.
-// A half-empty wave costs its full VALU cycles -- affordable exactly because the VALU is mostly idle here.
-template <uint32_t LPW = 64>
-__global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a)
-{
-  __shared__ uint32_t lds[LZD_LDS_DW];
-  const uint32_t tid = threadIdx.x;
-  const size_t c = LPW == 64 ? (size_t)blockIdx.x * LZ_BLOCK + tid
-                             : (size_t)blockIdx.x * (4u * LPW) + (tid >> 6) * LPW + ((tid & 63u) < LPW ? (tid & 63u) : a.C);
-  uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + tid);
-  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_SYM + tid);
-  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZD_OFF_CNT + tid);
+// The decoder runs as pairs of waves too (see the encoder): of 64 channels' two waves on one SIMD the first READS --
+// code register, recent offsets, frequency list: one token (a byte, or length << 8 | offset) per pass -- and the second
+// WRITES: history ring, match copies, 8-byte output stores.  Each wave has every lane filled (the single-wave kernel ran
+// batches of up to 64 Ki channels with half-filled waves to get two of them onto a SIMD, at twice the instructions).
+//   reader publishes: tokens written (mod 2^16) | no more will come << 24
+//   writer publishes: tokens taken (mod 2^16)   | the lane wants no more (output full) << 16
+constexpr uint32_t LZD_TOK_RING = 8;
+constexpr uint32_t LZD_OFF_TOK = LZD_LDS_DW, LZD_OFF_PUB = LZD_OFF_TOK + LZD_TOK_RING * LZ_BLOCK, LZD_PAIR_LDS_DW = LZD_OFF_PUB + 2 * LZ_BLOCK;
+constexpr uint32_t LZD_THREADS = 2 * LZ_BLOCK; // LZ_BLOCK channels per workgroup, two waves per 64 of them
+
 #define LZ_HIST8(b) hist8[((b) >> 2) * (4u * LZ_BLOCK) + ((b) & 3u)]
 #define LZ_SYM8(i) sym8[((i) >> 2) * (4u * LZ_BLOCK) + ((i) & 3u)]
 #define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
-  for (uint32_t k = 0; k < LZD_LDS_DW / LZ_BLOCK; k++)
-    lds[k * LZ_BLOCK + tid] = 0;
-  if (c >= a.C)
-    return;
 
-  const uint64_t nbits = a.in_bits[c];
-  const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + c * a.cap);
-  uint8_t *const dst = a.out + c * a.stride;
+// ---- the reading wave ------------------------------------------------------------------------------------------------
+DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
+{
+  uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_SYM + slot);
+  uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZD_OFF_CNT + slot);
+  const uint32_t *const symd = lds + LZD_OFF_SYM + slot;
+  uint32_t *const tok = lds + LZD_OFF_TOK + slot;
+  uint32_t *const pub_mine = lds + LZD_OFF_PUB + slot;
+  const uint32_t *const pub_peer = pub_mine + LZ_BLOCK;
+
+  const uint64_t nbits = live ? a.in_bits[c] : 0;
+  const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
   const uint32_t last_word = a.cap >= 4 ? (uint32_t)(a.cap / 4 - 1) : 0;
-  int32_t err = (nbits > 8ull * a.cap || a.cap < 4) ? ERR_INVALID_VALUE : OK;
+  const bool bad = nbits > 8ull * a.cap || a.cap < 4;
 
   uint64_t ip = 0;            // next input bit
   uint32_t wi = 0;            // index of w0
   uint32_t w0 = 0, w1 = 0, w2 = 0; // stream words wi, wi+1, wi+2 (w2 is the one in flight)
-  if (err == OK)
+  if (live && !bad)
   {
     w0 = bswap32(src[0]);
     w1 = bswap32(src[1 < last_word ? 1 : last_word]);
@@ -765,12 +766,247 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
   }
   uint32_t code_sym = 0;
   int32_t code_length = 0;
-  uint32_t hp = 0, mru = 0;
+  uint32_t mru = 0;
   uint32_t nvalid = 0; // entries 0 .. nvalid-1 of the list are in use (count > 0), entry nvalid is the first free one
-  const uint32_t *const symd = lds + LZD_OFF_SYM + tid;
+  uint32_t wr = 0;     // tokens handed over
+  bool finished = !live || bad;
+  bool stop = false;   // the writer wants no more of this channel
+
+  // one pass of the reference's loop body up to the point where it writes (lzmh.c:410-560): the next token, if any
+  auto next_token = [&](uint32_t &token, bool &emitted) {
+    // ---- top the register up to 25 bits (lzmh.c:410-415); bits shifted in while code_length <= 0 fall off ----
+    while (ip < nbits && code_length <= 24)
+    {
+      const uint64_t avail = nbits - ip;
+      uint32_t k;
+      bool lost = false;
+      if (code_length < 0)
+      {
+        k = (uint32_t)(-code_length);
+        lost = true;
+      }
+      else
+        k = 25u - (uint32_t)code_length;
+      k = avail < k ? (uint32_t)avail : k;
+      const uint32_t sh = (uint32_t)(ip & 31u);
+      const uint64_t two = ((uint64_t)w0 << 32) | w1;
+      const uint32_t chunk = (uint32_t)((two << sh) >> (64u - k)); // k in 1..25
+      if (!lost)
+        code_sym |= chunk << (32u - (uint32_t)code_length - k);
+      code_length += (int32_t)k;
+      ip += k;
+      const uint32_t nwi = (uint32_t)(ip >> 5);
+      if (nwi != wi)
+      {
+        wi = nwi;
+        w0 = w1;
+        w1 = w2;
+        const uint32_t idx = wi + 2u;
+        w2 = bswap32(src[idx < last_word ? idx : last_word]);
+      }
+    }
+    if ((code_sym & 0x80000000u) != 0) // list code
+    {
+      uint32_t len;
+      uint32_t i = lz_list_position(code_sym >> 24, len);
+      if (code_length < (int32_t)len)
+        i = LZ_TREE; // the code is cut off by the end of the stream: no table entry matches (lzmh.c:423)
+      if (i == LZ_TREE)
+      {
+        finished = true; // unknown code: the reference returns NO_ERROR here
+        return;
+      }
+      // the entry, its count and the two entries in front of it in one round of LDS reads (the bubble-up rarely goes further)
+      const uint32_t p1 = i > 0 ? i - 1u : 0u, p2 = i > 1 ? i - 2u : 0u;
+      const uint32_t sym = LZ_SYM8(i), c0 = LZ_CNT(i), c1 = LZ_CNT(p1), c2 = LZ_CNT(p2), s1 = LZ_SYM8(p1), s2 = LZ_SYM8(p2);
+      code_length -= (int32_t)len;
+      code_sym <<= len;
+      token = sym;
+      emitted = true;
+      if (c0 < 65535u)
+      {
+        if (i > 0 && c0 + 1u > c1)
+        {
+          LZ_SYM8(i) = (uint8_t)s1;
+          i--;
+          if (i > 0 && c0 + 1u > c2)
+          {
+            LZ_SYM8(i) = (uint8_t)s2;
+            i--;
+            while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
+            {
+              LZ_SYM8(i) = LZ_SYM8(i - 1u);
+              i--;
+            }
+          }
+        }
+        LZ_CNT(i) = (uint16_t)(c0 + 1u);
+        LZ_SYM8(i) = (uint8_t)sym;
+        if (i == nvalid) // only a damaged stream names an entry that is not in use yet
+          for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
+            ;
+      }
+    }
+    else if ((code_sym & 0x40000000u) == 0) // 00 + byte
+    {
+      const uint32_t sym = (code_sym >> 22) & 0xFFu;
+      code_length -= 10;
+      code_sym <<= 10;
+      token = sym;
+      emitted = true;
+      // the reference walks the list until the symbol or the first unused entry (:463-465); here the symbol dwords are
+      // searched byte-parallel in one round of LDS reads and the first unused entry is known (nvalid)
+      uint32_t i = nvalid;
+      {
+        const uint32_t splat = sym * 0x01010101u;
+#pragma unroll
+        for (uint32_t k = LZ_SYM_DW; k-- > 0;)
+        {
+          const uint32_t z = lz_zero_bytes_exact(symd[k * LZ_BLOCK] ^ splat);
+          const uint32_t p = 4u * k + ((uint32_t)__builtin_ctz(z | 0x80000000u) >> 3);
+          i = (z != 0 && p < i) ? p : i; // a hit at or above nvalid is a stale byte
+        }
+      }
+      if (i < LZ_LIST)
+      {
+        const uint32_t c0 = LZ_CNT(i);
+        if (c0 < 65535u)
+        {
+          while (i > 0 && c0 + 1u > LZ_CNT(i - 1u)) // whole entries move here (:470-474)
+          {
+            LZ_SYM8(i) = LZ_SYM8(i - 1u);
+            LZ_CNT(i) = LZ_CNT(i - 1u);
+            i--;
+          }
+          LZ_CNT(i) = (uint16_t)(c0 + 1u);
+          LZ_SYM8(i) = (uint8_t)sym;
+          if (i == nvalid)
+            for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
+              ;
+        }
+      }
+    }
+    else // match
+    {
+      uint32_t offset, length;
+      code_length -= 2;
+      code_sym <<= 2;
+      if ((code_sym & 0x80000000u) == 0)
+      {
+        offset = ((code_sym >> 24) & 0x7Fu) + 1u;
+        code_length -= 8;
+        code_sym <<= 8;
+        mru = (mru << 8) | offset;
+      }
+      else
+      {
+        code_length -= 1;
+        code_sym <<= 1;
+        if ((code_sym & 0x80000000u) == 0)
+          offset = mru & 0xFFu;
+        else
+        {
+          code_length -= 1;
+          code_sym <<= 1;
+          if ((code_sym & 0x80000000u) == 0)
+          {
+            offset = (mru >> 8) & 0xFFu;
+            mru = (mru & 0xFFFF0000u) | ((mru & 0xFFu) << 8) | offset;
+          }
+          else
+          {
+            code_length -= 1;
+            code_sym <<= 1;
+            if ((code_sym & 0x80000000u) == 0)
+            {
+              offset = (mru >> 16) & 0xFFu;
+              mru = (mru & 0xFF000000u) | ((mru & 0xFFFFu) << 8) | offset;
+            }
+            else
+            {
+              offset = mru >> 24;
+              mru = (mru << 8) | offset;
+            }
+          }
+        }
+        code_length -= 1;
+        code_sym <<= 1;
+      }
+      if ((code_sym & 0x80000000u) == 0)
+      {
+        length = ((code_sym >> 28) & 7u) + 3u;
+        code_length -= 4;
+        code_sym <<= 4;
+      }
+      else
+      {
+        code_length -= 1;
+        code_sym <<= 1;
+        if ((code_sym & 0x80000000u) == 0)
+        {
+          length = ((code_sym >> 28) & 7u) + 11u;
+          code_length -= 4;
+          code_sym <<= 4;
+        }
+        else
+        {
+          length = ((code_sym >> 23) & 0xFFu) + 19u;
+          code_length -= 9;
+          code_sym <<= 9;
+        }
+      }
+      token = (length << 8) | offset;
+      emitted = true;
+    }
+  };
+
+  for (;;)
+  {
+    const uint32_t peer = peer_load(pub_peer);
+    stop = stop || (peer & LZ_PUB_FINAL) != 0u;
+    const bool todo = !finished && !stop;
+    if (!wave_any(todo))
+      break;
+    const bool active = todo && ((wr - peer) & 0xFFFFu) < LZD_TOK_RING;
+    if (!wave_any(active))
+    {
+      wave_sleep<1>();
+      continue;
+    }
+    if (active)
+    {
+      uint32_t token = 0;
+      bool emitted = false;
+      next_token(token, emitted);
+      if (emitted)
+      {
+        tok[(wr % LZD_TOK_RING) * LZ_BLOCK] = token;
+        wr++;
+      }
+      finished = finished || !(ip < nbits || code_sym > 0); // the loop condition of lzmh.c:571 (its error half is the writer's)
+    }
+    peer_store(pub_mine, (wr & 0xFFFFu) | ((finished || stop) ? LZ_PUB_DONE : 0u));
+  }
+  peer_store(pub_mine, (wr & 0xFFFFu) | LZ_PUB_DONE);
+}
+
+// ---- the writing wave ------------------------------------------------------------------------------------------------
+DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
+{
+  uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + slot);
+  const uint32_t *const tok = lds + LZD_OFF_TOK + slot;
+  const uint32_t *const pub_peer = lds + LZD_OFF_PUB + slot;
+  uint32_t *const pub_mine = lds + LZD_OFF_PUB + LZ_BLOCK + slot;
+
+  const uint64_t nbits = live ? a.in_bits[c] : 0;
+  uint8_t *const dst = a.out + (live ? c : 0) * a.stride;
+  int32_t err = (nbits > 8ull * a.cap || a.cap < 4) ? ERR_INVALID_VALUE : OK;
+  uint32_t hp = 0;
   uint64_t obuf = 0;
   uint32_t nob = 0;
   uint64_t olen = 0;
+  uint32_t rd = 0;
+  uint32_t peer = peer_load(pub_peer); // (one pass old when it is used: see the DEGA coding waves)
 
   // one decoded byte: history ring + 8-byte output accumulator
 #define LZ_EMIT(b)                                                  \
@@ -792,208 +1028,77 @@ __global__ void __launch_bounds__(256) lzmh_decode_kernel(const LzmhDecodeArgs a
     }                                                               \
   } while (0)
 
-  if (err == OK)
-    do
+  for (;;)
+  {
+    const bool has = live && ((peer - rd) & 0xFFFFu) != 0u && err == OK;
+    const bool peer_done = (peer & LZ_PUB_DONE) != 0u;
+    const uint32_t token = tok[(rd % LZD_TOK_RING) * LZ_BLOCK];
+    peer = peer_load(pub_peer);
+    if (!wave_any(has))
     {
-      // ---- top the register up to 25 bits (lzmh.c:410-415); bits shifted in while code_length <= 0 fall off ----
-      while (ip < nbits && code_length <= 24)
+      if (wave_all(!live || peer_done || err != OK))
+        break;
+      wave_sleep<1>();
+      continue;
+    }
+    if (has)
+    {
+      rd++;
+      if (token < 0x100u)
+        LZ_EMIT(token);
+      else
       {
-        const uint64_t avail = nbits - ip;
-        uint32_t k;
-        bool lost = false;
-        if (code_length < 0)
-        {
-          k = (uint32_t)(-code_length);
-          lost = true;
-        }
-        else
-          k = 25u - (uint32_t)code_length;
-        k = avail < k ? (uint32_t)avail : k;
-        const uint32_t sh = (uint32_t)(ip & 31u);
-        const uint64_t two = ((uint64_t)w0 << 32) | w1;
-        const uint32_t chunk = (uint32_t)((two << sh) >> (64u - k)); // k in 1..25
-        if (!lost)
-          code_sym |= chunk << (32u - (uint32_t)code_length - k);
-        code_length += (int32_t)k;
-        ip += k;
-        const uint32_t nwi = (uint32_t)(ip >> 5);
-        if (nwi != wi)
-        {
-          wi = nwi;
-          w0 = w1;
-          w1 = w2;
-          const uint32_t idx = wi + 2u;
-          w2 = bswap32(src[idx < last_word ? idx : last_word]);
-        }
-      }
-      if ((code_sym & 0x80000000u) != 0) // list code
-      {
-        uint32_t len;
-        uint32_t i = lz_list_position(code_sym >> 24, len);
-        if (code_length < (int32_t)len)
-          i = LZ_TREE; // the code is cut off by the end of the stream: no table entry matches (lzmh.c:423)
-        if (i == LZ_TREE)
-          break; // unknown code: the reference returns NO_ERROR here
-        // the entry, its count and the two entries in front of it in one round of LDS reads (the bubble-up rarely goes further)
-        const uint32_t p1 = i > 0 ? i - 1u : 0u, p2 = i > 1 ? i - 2u : 0u;
-        const uint32_t sym = LZ_SYM8(i), c0 = LZ_CNT(i), c1 = LZ_CNT(p1), c2 = LZ_CNT(p2), s1 = LZ_SYM8(p1), s2 = LZ_SYM8(p2);
-        code_length -= (int32_t)len;
-        code_sym <<= len;
-        LZ_EMIT(sym);
-        if (c0 < 65535u)
-        {
-          if (i > 0 && c0 + 1u > c1)
-          {
-            LZ_SYM8(i) = (uint8_t)s1;
-            i--;
-            if (i > 0 && c0 + 1u > c2)
-            {
-              LZ_SYM8(i) = (uint8_t)s2;
-              i--;
-              while (i > 0 && c0 + 1u > LZ_CNT(i - 1u))
-              {
-                LZ_SYM8(i) = LZ_SYM8(i - 1u);
-                i--;
-              }
-            }
-          }
-          LZ_CNT(i) = (uint16_t)(c0 + 1u);
-          LZ_SYM8(i) = (uint8_t)sym;
-          if (i == nvalid) // only a damaged stream names an entry that is not in use yet
-            for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
-              ;
-        }
-      }
-      else if ((code_sym & 0x40000000u) == 0) // 00 + byte
-      {
-        const uint32_t sym = (code_sym >> 22) & 0xFFu;
-        code_length -= 10;
-        code_sym <<= 10;
-        LZ_EMIT(sym);
-        // the reference walks the list until the symbol or the first unused entry (:463-465); here the symbol dwords are
-        // searched byte-parallel in one round of LDS reads and the first unused entry is known (nvalid)
-        uint32_t i = nvalid;
-        {
-          const uint32_t splat = sym * 0x01010101u;
-#pragma unroll
-          for (uint32_t k = LZ_SYM_DW; k-- > 0;)
-          {
-            const uint32_t z = lz_zero_bytes_exact(symd[k * LZ_BLOCK] ^ splat);
-            const uint32_t p = 4u * k + ((uint32_t)__builtin_ctz(z | 0x80000000u) >> 3);
-            i = (z != 0 && p < i) ? p : i; // a hit at or above nvalid is a stale byte
-          }
-        }
-        if (i < LZ_LIST)
-        {
-          const uint32_t c0 = LZ_CNT(i);
-          if (c0 < 65535u)
-          {
-            while (i > 0 && c0 + 1u > LZ_CNT(i - 1u)) // whole entries move here (:470-474)
-            {
-              LZ_SYM8(i) = LZ_SYM8(i - 1u);
-              LZ_CNT(i) = LZ_CNT(i - 1u);
-              i--;
-            }
-            LZ_CNT(i) = (uint16_t)(c0 + 1u);
-            LZ_SYM8(i) = (uint8_t)sym;
-            if (i == nvalid)
-              for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
-                ;
-          }
-        }
-      }
-      else // match
-      {
-        uint32_t offset, length;
-        code_length -= 2;
-        code_sym <<= 2;
-        if ((code_sym & 0x80000000u) == 0)
-        {
-          offset = ((code_sym >> 24) & 0x7Fu) + 1u;
-          code_length -= 8;
-          code_sym <<= 8;
-          mru = (mru << 8) | offset;
-        }
-        else
-        {
-          code_length -= 1;
-          code_sym <<= 1;
-          if ((code_sym & 0x80000000u) == 0)
-            offset = mru & 0xFFu;
-          else
-          {
-            code_length -= 1;
-            code_sym <<= 1;
-            if ((code_sym & 0x80000000u) == 0)
-            {
-              offset = (mru >> 8) & 0xFFu;
-              mru = (mru & 0xFFFF0000u) | ((mru & 0xFFu) << 8) | offset;
-            }
-            else
-            {
-              code_length -= 1;
-              code_sym <<= 1;
-              if ((code_sym & 0x80000000u) == 0)
-              {
-                offset = (mru >> 16) & 0xFFu;
-                mru = (mru & 0xFF000000u) | ((mru & 0xFFFFu) << 8) | offset;
-              }
-              else
-              {
-                offset = mru >> 24;
-                mru = (mru << 8) | offset;
-              }
-            }
-          }
-          code_length -= 1;
-          code_sym <<= 1;
-        }
-        if ((code_sym & 0x80000000u) == 0)
-        {
-          length = ((code_sym >> 28) & 7u) + 3u;
-          code_length -= 4;
-          code_sym <<= 4;
-        }
-        else
-        {
-          code_length -= 1;
-          code_sym <<= 1;
-          if ((code_sym & 0x80000000u) == 0)
-          {
-            length = ((code_sym >> 28) & 7u) + 11u;
-            code_length -= 4;
-            code_sym <<= 4;
-          }
-          else
-          {
-            length = ((code_sym >> 23) & 0xFFu) + 19u;
-            code_length -= 9;
-            code_sym <<= 9;
-          }
-        }
+        const uint32_t offset = token & 0xFFu, length = token >> 8;
         for (uint32_t k = 0; k < length && err == OK; k++)
         {
           const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
           LZ_EMIT(sym);
         }
       }
-    } while (err == OK && (ip < nbits || code_sym > 0));
-
-  if (err == OK && nob > 0)
-  {
-    if (olen + 8u > a.stride)
-      err = ERR_MEMORY;
-    else
-      *reinterpret_cast<uint64_t *>(dst + olen) = obuf;
-    olen += nob;
+    }
+    peer_store(pub_mine, (rd & 0xFFFFu) | (err != OK ? LZ_PUB_FINAL : 0u));
   }
-  a.out_len[c] = err == OK ? olen : 0;
-  a.err[c] = err;
+  peer_store(pub_mine, (rd & 0xFFFFu) | LZ_PUB_FINAL);
+
+  if (live)
+  {
+    if (err == OK && nob > 0)
+    {
+      if (olen + 8u > a.stride)
+        err = ERR_MEMORY;
+      else
+        *reinterpret_cast<uint64_t *>(dst + olen) = obuf;
+      olen += nob;
+    }
+    a.out_len[c] = err == OK ? olen : 0;
+    a.err[c] = err;
+  }
 #undef LZ_EMIT
+}
+
+__global__ void __launch_bounds__(LZD_THREADS) lzmh_decode_kernel(const LzmhDecodeArgs a)
+{
+  __shared__ uint32_t lds[LZD_PAIR_LDS_DW];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = wave_uniform(threadIdx.x >> 6);
+  const uint32_t slot = (wave % 4u) * 64u + lane; // the channel's column in every LDS array
+  const bool writes = wave >= 4u;
+  const size_t c = (size_t)blockIdx.x * LZ_BLOCK + slot;
+  const bool live = c < a.C;
+  if (!writes) // history, list (entries never written read as symbol 0), token ring, published words: all zero
+    for (uint32_t k = 0; k < LZD_PAIR_LDS_DW / LZ_BLOCK; k++)
+      lds[k * LZ_BLOCK + slot] = 0;
+  __syncthreads();
+  if (!wave_any(live))
+    return;
+  if (writes)
+    lzmh_writing_wave(a, lds, slot, c, live);
+  else
+    lzmh_reading_wave(a, lds, slot, c, live);
+}
 #undef LZ_HIST8
 #undef LZ_SYM8
 #undef LZ_CNT
-}
 
 // ASCII rendering of the synthetic meter channels for the LZMH workload (cfg 4): channel c's samples
 // x[t][c] (centi-units) as "%d.%02d\n" lines -- the "ASCII float in" domain of the reference's LZMH (DCLib/doc/readme.md:30).

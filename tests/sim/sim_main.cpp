@@ -275,7 +275,7 @@ extern "C" __attribute__((visibility("default"))) int sim_lzmh_render(const int3
 extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
 {
   LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
-  sim::launch(lzmh_decode_kernel<64>, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZ_BLOCK), a);
+  sim::launch(lzmh_decode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZD_THREADS), a);
   return 0;
 }
 
@@ -333,6 +333,6 @@ extern "C" __attribute__((visibility("default"))) int sim_decode64(const uint8_t
 extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode_half(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride, uint64_t *out_len, int32_t *err)
 {
   LzmhDecodeArgs a{in, cap, in_bits, C, out, stride, out_len, err};
-  sim::launch(lzmh_decode_kernel<32>, dim3((unsigned)((C + 127) / 128)), dim3(LZ_BLOCK), a);
+  sim::launch(lzmh_decode_kernel, dim3((unsigned)((C + LZ_BLOCK - 1) / LZ_BLOCK)), dim3(LZD_THREADS), a); // (one shape since the pairs of waves)
   return 0;
 }
