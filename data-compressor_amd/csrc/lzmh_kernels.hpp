@@ -994,6 +994,7 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
 DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
 {
   uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + slot);
+  const uint32_t *const histd = lds + LZD_OFF_HIST + slot; // dword d of the ring: histd[d * LZ_BLOCK]
   const uint32_t *const tok = lds + LZD_OFF_TOK + slot;
   const uint32_t *const pub_peer = lds + LZD_OFF_PUB + slot;
   uint32_t *const pub_mine = lds + LZD_OFF_PUB + LZ_BLOCK + slot;
@@ -1049,7 +1050,21 @@ DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
       else
       {
         const uint32_t offset = token & 0xFFu, length = token >> 8;
-        for (uint32_t k = 0; k < length && err == OK; k++)
+        uint32_t k = 0;
+        // four bytes per round while the source lies at least four bytes back (none of them is written in this round):
+        // one LDS latency for four bytes instead of four -- the copy is a chain of dependent LDS round trips
+        if (offset >= 4u)
+          for (; k + 4u <= length && err == OK; k += 4u)
+          {
+            const uint32_t from = (hp - offset) & (LZ_HISTORY - 1u);
+            const uint32_t d0 = histd[(from >> 2) * LZ_BLOCK], d1 = histd[(((from >> 2) + 1u) & (LZ_HISTORY / 4u - 1u)) * LZ_BLOCK];
+            const uint32_t four = lz_alignbyte(d1, d0, from & 3u);
+            LZ_EMIT(four & 0xFFu);
+            LZ_EMIT((four >> 8) & 0xFFu);
+            LZ_EMIT((four >> 16) & 0xFFu);
+            LZ_EMIT(four >> 24);
+          }
+        for (; k < length && err == OK; k++)
         {
           const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
           LZ_EMIT(sym);
