@@ -1,9 +1,10 @@
 // lzmh_kernels.hpp -- LZMH (BASELINE config 4) for gfx950: the reference's second codec, DCLib/src/lzmh.c:130-574.
 // Encode kernel first (this comment), decode kernel and the ASCII rendering of the workload further down.
 //
-// Mapping: one lane = one channel (an independent byte string), one wave = 64 channels, one workgroup = 4 waves.
-// The codec is serial per channel (every code depends on the match window, the recent-offset cache and the frequency
-// list left by the previous one), so -- as for DEGA -- all parallelism is across channels.
+// Mapping: one lane = one channel (an independent byte string), one wave = 64 channels, one workgroup = 4 PAIRS of waves:
+// of each pair one wave searches (decode: reads the code), its partner on the same SIMD codes (decode: writes) -- see the
+// kernels.  The codec is serial per channel (every code depends on the match window, the recent-offset cache and the
+// frequency list left by the previous one), so -- as for DEGA -- all parallelism is across channels.
 //
 // What the reference does per step, restated without its 403-byte ring (lzmh.c:143-146, 174-191, 343-363): with P
 // bytes consumed so far, look back at most min(P, 128) bytes and ahead at most min(274, min(n, max(P-128, 0) + 403) - P)
@@ -16,12 +17,14 @@
 //            and a byte-parallel compare marks every position whose first three bytes equal the next three input bytes:
 //            per dword 2 v_alignbyte, 3 xor, or3, a zero-byte test and a multiply that gathers the four flags -- 11
 //            instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
-//   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass, and each is
-//            measured against the 16 input bytes held in registers (all LDS reads of a pass in flight together);
-//            `len > best` in that order keeps the nearest of equals.
-// Window: 432 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for the whole wave when a lane
-// runs out of look-ahead (every ~270 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count})
-// and four staged output words per lane are in LDS as well: 152 KiB per workgroup, one workgroup per CU.
+//   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass of the wave's
+//            loop, and measured against the input bytes held in registers -- the first 8 bytes of all five, then the
+//            next 8 of the few that match those (all LDS reads of a round in flight together); `len > best` in that
+//            order keeps the nearest of equals.  A lane with more candidates keeps its step and takes further passes
+//            while the other lanes go on to their next steps.
+// Window: 432 bytes per lane in LDS ([dword][lane], conflict free), reloaded from HBM for every lane with work when one
+// runs out of look-ahead (every ~270 consumed bytes; L2 absorbs the overlap).  Frequency list (48 x {symbol, count}),
+// four staged output words and the token ring per lane are in LDS as well: 158 KiB per workgroup, one workgroup per CU.
 //
 // Compiled by hipcc (dega_hip.hip) and, for offline debugging only, by g++ under tests/sim/.
 #pragma once
