@@ -206,6 +206,7 @@ DG_DEV void peer_store(uint32_t *lds_word, uint32_t v)
 DG_DEV uint32_t peer_load(const uint32_t *lds_word)
 {
 #if defined(DEGA_SIM)
+  sim::drag(); // (emulator test knob: a slow partner, tests/sim/hipsim.hpp)
   return __atomic_load_n(lds_word, __ATOMIC_ACQUIRE);
 #else
   DG_COMPILER_BARRIER();

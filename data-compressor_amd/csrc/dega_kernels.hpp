@@ -366,8 +366,11 @@ DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_
         lost = true;
     }
   }
-  // the last, partial word of the seg stream goes into the next ring slot, left aligned (the slot is free: a batch's
-  // worst case counts it)
+  // the last, partial word of the seg stream goes into the next ring slot, left aligned -- once that slot is free: a
+  // batch of worst-case codewords can leave the ring full to the last slot (RING words queued), and the next slot is
+  // then the oldest word the coder has not taken yet
+  while (wave_any(((q.wr - peer_load(pub_peer)) & 0xFFFFu) >= RING))
+    wave_sleep<DG_ENC_FILL_SLEEP>();
   ring_col[(q.wr % RING) * 64u] = q.cnt != 0u ? (uint32_t)(q.acc << (32u - q.cnt)) : 0u;
   peer_store(pub_mine, (q.wr & 0xFFFFu) | (q.cnt << 16) | ENC_PUB_DONE | (lane_err != OK ? ENC_PUB_BAD : 0u) | (lost ? ENC_PUB_LOST : 0u));
 }

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include <barrier>
+#include <chrono>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -29,6 +30,15 @@ inline dim3 g_blockDim, g_gridDim;
 inline std::unique_ptr<std::barrier<>> g_block_barrier;
 inline std::vector<std::unique_ptr<std::barrier<>>> g_wave_barrier;
 inline uint8_t g_votes[16][64];
+
+// Test knob: the waves g_drag_from .. of a workgroup sleep g_drag_us microseconds whenever they read a word of their
+// partner (peer_load) -- a slow consumer, so that the rings between paired waves run full.
+inline int g_drag_from = 1 << 30, g_drag_us = 0;
+inline void drag()
+{
+  if ((int)(t_threadIdx.x >> 6) >= g_drag_from && g_drag_us > 0)
+    std::this_thread::sleep_for(std::chrono::microseconds(g_drag_us));
+}
 
 inline void block_barrier()
 {

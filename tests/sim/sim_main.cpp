@@ -25,6 +25,12 @@ static std::vector<uint32_t> make_table()
   return tab;
 }
 
+extern "C" __attribute__((visibility("default"))) void sim_set_drag(int from_wave, int microseconds)
+{
+  sim::g_drag_from = from_wave;
+  sim::g_drag_us = microseconds;
+}
+
 extern "C" __attribute__((visibility("default"))) int sim_encode_vs(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, int valuesize, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();

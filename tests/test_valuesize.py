@@ -382,6 +382,37 @@ def test_kernel_logic_with_valuesize_above_32(sim, gold64):
     _roundtrip64(gold64, (40, 64), encode, decode_var)
 
 
+def test_last_partial_word_waits_for_its_ring_slot(sim):
+    """Worst-case codewords (125 bits each) up to the last row, and a coding wave that is slow to take words (emulator
+    knob): the filling wave's last batch leaves the seg-bit ring full to the last slot, so the channel's final, partial
+    word may only be written once the coder has freed the slot it goes to -- written at once it replaced the oldest
+    queued word (found as a rare failure of the test above under load; whether a given run would hit it depends on
+    the threads' timing, so this test raises the odds rather than proving the absence)."""
+    _sim64(sim)
+    sim.sim_set_drag.argtypes = [C.c_int, C.c_int]
+    rng = np.random.default_rng(1)
+    T, Cn, vs = 64, 64, 63
+    x = np.zeros((T, Cn), dtype=np.uint64)
+    for c in range(Cn):
+        x[1::2, c] = np.uint64(2**62 - 1) - rng.integers(0, 5, T // 2).astype(np.uint64)
+    xin = np.ascontiguousarray(x.view(np.int64))
+    cap = 4 * ((T * 40 + 64) // 4)
+    out = np.zeros((Cn, cap), dtype=np.uint8)
+    bits = np.zeros(Cn, dtype=np.uint64)
+    err = np.zeros(Cn, dtype=np.int32)
+    sim.sim_set_drag(4, 200)  # waves 4..7 of the workgroup are the coding waves: 200 us per step
+    try:
+        sim.sim_encode64(xin.ctypes.data, Cn, T, Cn, 1, vs, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+    finally:
+        sim.sim_set_drag(1 << 30, 0)
+    for c in range(Cn):
+        d, n = pack_be(x[:, c], vs)
+        for name in ("diff", "seg", "bac"):
+            r, d, n = orc.stage(name, True, d, n, valuesize=vs, adaptive=1)
+            assert r == 0
+        assert int(err[c]) == 0 and int(bits[c]) == n and out[c, : (n + 7) // 8].tobytes() == d[: (n + 7) // 8], c
+
+
 @pytest.mark.gpu
 def test_gpu_valuesize_above_32(gold64):
     from __graft_entry__ import load_package
