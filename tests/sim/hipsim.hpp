@@ -6,7 +6,9 @@
 // (ring indexing, phase control, termination) against the oracle before spending GPU minutes.  Speed: ~1e4x slower
 // than the GPU.  Model: one OS thread per lane; a workgroup's threads run concurrently, workgroups run one after
 // the other; __syncthreads() and the wave votes are barriers (valid because the kernels only vote in wave-uniform
-// control flow).
+// control flow).  The paired waves of the kernels (one codes, its partner fills / parses / searches) therefore run
+// truly concurrently here and talk through their LDS words with release / acquire (dega_intrinsics.hpp: peer_store /
+// peer_load); sim::drag() below slows one side down for tests that want a ring to run full.
 #pragma once
 
 #include <stdint.h>
