@@ -203,6 +203,12 @@ constexpr uint32_t LZ_TOK_RING = 8;
 constexpr uint32_t LZ_TOK_RING = LZ_TOK_RING_OVERRIDE; // (stress builds of the emulator)
 #endif
 constexpr uint32_t LZ_PUB_DONE = 1u << 24, LZ_PUB_FINAL = 1u << 16;
+#ifndef DG_LZ_SEARCH_PRIO // issue priority of the searching / reading waves (tools/tunebench.py)
+#define DG_LZ_SEARCH_PRIO 0
+#endif
+#ifndef DG_LZ_READ_PRIO
+#define DG_LZ_READ_PRIO 0
+#endif
 constexpr uint32_t LZ_OFF_TOK = LZ_LDS_DW, LZ_OFF_PUB = LZ_OFF_TOK + LZ_TOK_RING * LZ_BLOCK, LZ_ENC_LDS_DW = LZ_OFF_PUB + 2 * LZ_BLOCK;
 static_assert(LZ_ENC_LDS_DW * 4 <= 160 * 1024, "LDS budget of one CU");
 constexpr uint32_t LZ_ENC_THREADS = 2 * LZ_BLOCK; // LZ_BLOCK channels per workgroup, two waves per 64 of them
@@ -237,6 +243,7 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
   // other lanes go on to their next steps meanwhile.  (In one lockstep step per lane the wave measured 25 candidates
   // per step for an average lane that has 2.)
   bool verifying = false;
+  wave_priority<DG_LZ_SEARCH_PRIO>();
   uint32_t cm[5] = {0, 0, 0, 0, 0}; // candidates left: bit i of the 132-bit mask = window position 4 * wd0 + i
   uint32_t best = 2, besto = 0;
   uint32_t T0 = 0, T1 = 0, T2 = 0, T3 = 0; // the next 16 input bytes
@@ -774,6 +781,7 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
   uint32_t wr = 0;     // tokens handed over
   bool finished = !live || bad;
   bool stop = false;   // the writer wants no more of this channel
+  wave_priority<DG_LZ_READ_PRIO>();
 
   // one pass of the reference's loop body up to the point where it writes (lzmh.c:410-560): the next token, if any
   auto next_token = [&](uint32_t &token, bool &emitted) {

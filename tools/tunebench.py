@@ -45,11 +45,32 @@ elif sys.argv[1] == "child":
         ctx.decode(out, bits, T, x_tc=y, err=derr)
     torch.cuda.synchronize()
     _, dms = ctx.profile_read(1)
-    print(json.dumps({"lib": os.path.basename(dca.LIB_PATH), "C": C_, "T": T, "encode_ms": round(ems, 3), "decode_ms": round(dms, 3),
-                      "round_trip_ok": bool((y == x).all()), "errors": int((err != 0).sum()) + int((derr != 0).sum())}), flush=True)
+    res = {"lib": os.path.basename(dca.LIB_PATH), "C": C_, "T": T, "encode_ms": round(ems, 3), "decode_ms": round(dms, 3),
+           "round_trip_ok": bool((y == x).all()), "errors": int((err != 0).sum()) + int((derr != 0).sum())}
+    if len(sys.argv) > 4 and sys.argv[4] == "lzmh":
+        TL = min(T, 4000)
+        stride = 16 * ((TL * 9 + 15) // 16)
+        text, lens, rerr = ctx.lzmh_render(x[:TL].contiguous(), stride)
+        lcap = 16 * ((stride * 3 // 4 + 63) // 16)
+        lout = torch.zeros((C_, lcap), dtype=torch.uint8, device="cuda"); lbits = torch.zeros(C_, dtype=torch.int64, device="cuda"); lerr = torch.zeros(C_, dtype=torch.int32, device="cuda")
+        ctx.lzmh_encode(text, lens, cap=lcap, out=lout, bits=lbits, err=lerr); torch.cuda.synchronize()
+        ctx.profile(True)
+        for _ in range(3):
+            ctx.lzmh_encode(text, lens, cap=lcap, out=lout, bits=lbits, err=lerr)
+        torch.cuda.synchronize()
+        _, lems = ctx.profile_read(2)
+        back = torch.zeros((C_, stride), dtype=torch.uint8, device="cuda")
+        ctx.lzmh_decode(lout, lbits, stride, out=back); torch.cuda.synchronize()
+        ctx.profile(True)
+        for _ in range(3):
+            ctx.lzmh_decode(lout, lbits, stride, out=back)
+        torch.cuda.synchronize()
+        _, ldms = ctx.profile_read(3)
+        res.update({"lzmh_encode_ms": round(lems, 3), "lzmh_decode_ms": round(ldms, 3)})
+    print(json.dumps(res), flush=True)
 else:
     C_, T = sys.argv[2], sys.argv[3]
     libs = [os.path.join(ROOT, "data-compressor_amd", "libdega_hip.so")] + sorted(
         os.path.join(DIAG, f) for f in os.listdir(DIAG) if f.startswith("libdega_hip_tune_") and f.endswith(".so"))
     for lib in libs:
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child", C_, T], env=dict(os.environ, DEGA_HIP_LIB=lib))
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child", C_, T] + sys.argv[4:], env=dict(os.environ, DEGA_HIP_LIB=lib))
