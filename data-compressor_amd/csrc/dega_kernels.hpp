@@ -1267,18 +1267,51 @@ struct GatherArgs
   uint8_t *packed;
 };
 
-// one wave per channel, byte granular (offsets are arbitrary), coalesced over the channel's bytes
+// One wave copies n bytes, any alignment on either side: bytes up to the destination's next 16-byte boundary, then 16
+// bytes per lane and round -- the source read as the five dwords that hold them at its own alignment, shifted into place
+// (v_alignbyte), one 16-byte store -- then the last few bytes.  Reads stay inside [src rounded down to 4, src + n).
+DG_DEV void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n, uint32_t lane)
+{
+  uint64_t head = (16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u;
+  head = head < n ? head : n;
+  if (lane < head)
+    dst[lane] = src[lane];
+  dst += head;
+  src += head;
+  n -= head;
+  const uint32_t sh = (uint32_t)((uintptr_t)src & 3u);
+  const uint32_t *const s4 = reinterpret_cast<const uint32_t *>(src - sh);
+  const uint64_t rounds = n >= 20u ? (n - 4u) / 16u : 0u;
+  for (uint64_t i = lane; i < rounds; i += 64)
+  {
+    const uint32_t *const p = s4 + 4u * i;
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+#if defined(DEGA_SIM)
+    const uint64_t q0 = ((uint64_t)w1 << 32) | w0, q1 = ((uint64_t)w2 << 32) | w1, q2 = ((uint64_t)w3 << 32) | w2, q3 = ((uint64_t)w4 << 32) | w3;
+    const uint32_t o0 = (uint32_t)(q0 >> (8u * sh)), o1 = (uint32_t)(q1 >> (8u * sh)), o2 = (uint32_t)(q2 >> (8u * sh)), o3 = (uint32_t)(q3 >> (8u * sh));
+#else
+    const uint32_t o0 = __builtin_amdgcn_alignbyte(w1, w0, sh), o1 = __builtin_amdgcn_alignbyte(w2, w1, sh), o2 = __builtin_amdgcn_alignbyte(w3, w2, sh),
+                   o3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+#endif
+    uint32_t *const d4 = reinterpret_cast<uint32_t *>(dst + 16u * i);
+    d4[0] = o0;
+    d4[1] = o1;
+    d4[2] = o2;
+    d4[3] = o3;
+  }
+  const uint64_t done = 16u * rounds;
+  if (done + lane < n) // fewer than 20 bytes are left
+    dst[done + lane] = src[done + lane];
+}
+
+// one wave per channel (offsets are arbitrary byte positions)
 __global__ void __launch_bounds__(256) dega_gather_kernel(const GatherArgs a)
 {
   const size_t c = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (c >= a.C)
     return;
-  const uint32_t lane = threadIdx.x & 63u;
   const uint64_t o0 = a.offsets[c], o1 = a.offsets[c + 1];
-  const uint8_t *src = a.slabs + c * a.cap;
-  uint8_t *dst = a.packed + o0;
-  for (uint64_t i = lane; i < o1 - o0; i += 64)
-    dst[i] = src[i];
+  wave_copy_bytes(a.packed + o0, a.slabs + c * a.cap, o1 - o0, threadIdx.x & 63u);
 }
 
 // the inverse: packed streams -> slabs (the decoders mask what lies beyond a stream's bit length, so nothing is padded)
@@ -1287,13 +1320,8 @@ __global__ void __launch_bounds__(256) dega_scatter_kernel(const GatherArgs a)
   const size_t c = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (c >= a.C)
     return;
-  const uint32_t lane = threadIdx.x & 63u;
   const uint64_t o0 = a.offsets[c], o1 = a.offsets[c + 1];
-  const uint8_t *src = a.packed + o0;
-  uint8_t *dst = const_cast<uint8_t *>(a.slabs) + c * a.cap;
-  const uint64_t n = o1 - o0 < a.cap ? o1 - o0 : a.cap;
-  for (uint64_t i = lane; i < n; i += 64)
-    dst[i] = src[i];
+  wave_copy_bytes(const_cast<uint8_t *>(a.slabs) + c * a.cap, a.packed + o0, o1 - o0 < a.cap ? o1 - o0 : a.cap, threadIdx.x & 63u);
 }
 
 } // namespace dg
