@@ -108,6 +108,7 @@ struct BacEncoder
   // lanes of a wave reach that point in different steps: handled by the general path, the wave spent a fifth of its
   // steps there.)
   uint32_t part_lo, part_hi;
+  bool part_halves; // the two parts meet at a halving of the counts (else: at a change of the division shift)
 
   DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
   {
@@ -130,6 +131,7 @@ struct BacEncoder
     cls = CLS_BITS;
     part_lo = 0;
     part_hi = 31;
+    part_halves = false;
   }
 
   DG_DEV uint32_t A() const
@@ -410,6 +412,18 @@ struct BacEncoder
       safe = 0;
       part_lo = 0;
       part_hi = MAX_FREQUENCY - tot; // 0..31: the update of this symbol halves
+      part_halves = true;
+    }
+    else if (w_halve != 0u && w_swap != 0u && w_shift == 0u && w8 != 0u)
+    {
+      // nothing but a change of the division shift in this word -- cum[0] passes a power of two, which it does ten times
+      // on its way up (short channels never get further) -- : the symbols up to cum[0] = 2^k and those after it are two
+      // plain fast parts, each with its own shift; the counts just go on counting
+      cls = CLS_SPLIT;
+      safe = 0;
+      part_lo = 0;
+      part_hi = pw - tot; // 0..30: the last symbol coded with the old shift
+      part_halves = false;
     }
     else
     {
@@ -435,10 +449,13 @@ struct BacEncoder
     if (part_lo == 0u)
     {
       const uint32_t h = part_hi;
-      const uint32_t lps = ((word >> (31u - h)) & 1u) ^ mps;
-      const uint32_t c1h = c1 - lps;                     // cum[1] when symbol h was coded; cum[0] was MAX_FREQUENCY
-      c1 = (c1h >> 1) + 1u + lps;                        // :60-66 (f2 + 1) / 2 + 1, then :78 (no tie: see classify)
-      tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u; // (f1 + 1) / 2 + (f2 + 1) / 2 + 1, then :80
+      if (part_halves)
+      {
+        const uint32_t lps = ((word >> (31u - h)) & 1u) ^ mps;
+        const uint32_t c1h = c1 - lps;                     // cum[1] when symbol h was coded; cum[0] was MAX_FREQUENCY
+        c1 = (c1h >> 1) + 1u + lps;                        // :60-66 (f2 + 1) / 2 + 1, then :78 (no tie: see classify)
+        tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u; // (f1 + 1) / 2 + (f2 + 1) / 2 + 1, then :80
+      }
       part_lo = h + 1u;
       part_hi = 31;
       if (h != 31u)
