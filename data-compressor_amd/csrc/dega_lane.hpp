@@ -838,9 +838,11 @@ struct BacDecoder
   // The symbols of the next word that the next masked word path decodes (as BacEncoder::part_lo / part_hi): all 32, or --
   // around a halving of the counts -- first 0 .. h, then, a step later, h+1 .. 31; part_bits keeps the first part's bits.
   uint32_t part_lo, part_hi, part_bits;
+  bool part_halves; // the first part ends at a halving of the counts (else: at a change of the division shift, or nowhere)
 
   DG_DEV void init()
   {
+    part_halves = false;
     A = 0;
     B = 0;
     D = 0;
@@ -949,15 +951,29 @@ struct BacDecoder
   // The next word holds a halving of the counts (bac.c:57) and nothing else the fast path cannot do -- or its first part
   // has been decoded already: the masked word path takes it, in two steps (see BacEncoder::classify, CLS_SPLIT: the
   // counts are in the top half of their range, and f1 - f2 >= 96 rules a swap out on both sides of the halving).
+  DG_DEV bool halving_ahead() const // the only event of the next word is a halving, with room to spare (see above)
+  {
+    return tot + 32u > MAX_FREQUENCY && tot <= MAX_FREQUENCY && tot + 1u >= 2u * c1 + 96u;
+  }
+
+  DG_DEV bool shift_change_ahead() const // the only event of the next word is cum[0] passing a power of two
+  {
+    return tot + 32u <= MAX_FREQUENCY && tot + 1u >= 2u * c1 + 32u && clz32(tot - 1u) != clz32(tot + 30u);
+  }
+
   DG_DEV bool split_ok() const
   {
-    return ADAPTIVE && (part_lo != 0u || (tot + 32u > MAX_FREQUENCY && tot <= MAX_FREQUENCY && tot + 1u >= 2u * c1 + 96u));
+    return ADAPTIVE && (part_lo != 0u || halving_ahead() || shift_change_ahead());
   }
 
   DG_DEV void begin_word() // before a masked word path: which symbols it decodes
   {
     if (part_lo == 0u)
-      part_hi = (tot + 32u > MAX_FREQUENCY) ? MAX_FREQUENCY - tot : 31u;
+    {
+      part_halves = halving_ahead();
+      const uint32_t pw = 0x80000000u >> (clz32(tot - 1u) - 1u); // the power of two cum[0] reaches next
+      part_hi = part_halves ? MAX_FREQUENCY - tot : (shift_change_ahead() ? pw - tot : 31u);
+    }
   }
 
   DG_DEV void whole_word()
@@ -968,29 +984,26 @@ struct BacDecoder
   }
 
   // After a masked word path that came through; `bits` = its symbols (the others zero).  Returns true when the word is
-  // complete (then `bits` is the whole word).  After the first part the update of symbol part_hi, which the word path
-  // applied as a plain count, is redone as UpdateModel does it: halve, count the symbol, cum[0]++ (BacEncoder::after_part).
+  // complete (then `bits` is the whole word).  After the first part of a halving word the update of symbol part_hi, which
+  // the word path applied as a plain count, is redone as UpdateModel does it: halve, count the symbol, cum[0]++
+  // (BacEncoder::after_part); at a change of the division shift the counts just go on.
   DG_DEV bool after_part(uint32_t &bits)
   {
     bits |= part_bits;
-    if (part_lo == 0u && part_hi != 31u)
+    if (part_lo == 0u && part_halves)
     {
       const uint32_t h = part_hi;
       const uint32_t lps = ((bits >> (31u - h)) & 1u) ^ mps;
       const uint32_t c1h = c1 - lps;
       c1 = (c1h >> 1) + 1u + lps;
       tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u;
-      part_lo = h + 1u;
+    }
+    if (part_lo == 0u && part_hi != 31u)
+    {
+      part_lo = part_hi + 1u;
       part_hi = 31;
       part_bits = bits;
       return false;
-    }
-    if (part_lo == 0u && tot == MAX_FREQUENCY + 1u) // the halving belongs to the last symbol of the word
-    {
-      const uint32_t lps = (bits & 1u) ^ mps;
-      const uint32_t c1h = c1 - lps;
-      c1 = (c1h >> 1) + 1u + lps;
-      tot = ((MAX_FREQUENCY + 1u - c1h) >> 1) + (c1h >> 1) + 2u;
     }
     part_lo = 0;
     part_hi = 31;
