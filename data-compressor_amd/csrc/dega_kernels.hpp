@@ -141,6 +141,9 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 #ifndef DG_DEC_CODE_PRIO
 #define DG_DEC_CODE_PRIO 0
 #endif
+#ifndef DG_DEC_TAKES // unconditional short-codeword takes per pass of the parsing wave
+#define DG_DEC_TAKES 5
+#endif
 constexpr uint32_t ENC_PAIRS = 4;
 constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
 constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
@@ -970,7 +973,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     // ---- parse what is there -------------------------------------------------------------------------------------------
     bool more = false;
     // (1) the steady state, branch free: short codewords off the top of the window; a lane that cannot take one writes to
-    //     a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data: four takes, then
+    //     a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data: five takes (measured: 3 .. 6 within 1 %, five best), then
     //     two more for as long as some lane's window would not have room for its next word
     if constexpr (!W64)
     {
@@ -984,7 +987,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
         return took;
       };
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
+      for (uint32_t k = 0; k < DG_DEC_TAKES; k++)
         more = take();
       while (wave_any(more && (!sp.has_room() || final_in)))
       {
