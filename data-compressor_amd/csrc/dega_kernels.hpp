@@ -142,7 +142,7 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 #define DG_DEC_CODE_PRIO 0
 #endif
 #ifndef DG_DEC_TAKES // unconditional short-codeword takes per pass of the parsing wave
-#define DG_DEC_TAKES 5
+#define DG_DEC_TAKES 4
 #endif
 constexpr uint32_t ENC_PAIRS = 4;
 constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
@@ -973,7 +973,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     // ---- parse what is there -------------------------------------------------------------------------------------------
     bool more = false;
     // (1) the steady state, branch free: short codewords off the top of the window; a lane that cannot take one writes to
-    //     a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data: five takes (measured: 3 .. 6 within 1 %, five best), then
+    //     a spare slot of its sample column instead.  A 32-bit word holds 3-4 codewords of this data: four takes (measured: 3 .. 6 are within 1 %), then
     //     two more for as long as some lane's window would not have room for its next word
     if constexpr (!W64)
     {
