@@ -369,18 +369,27 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
     if (wave_any(verifying && best < lim && (cm[0] | cm[1] | cm[2] | cm[3] | cm[4]) != 0u))
     {
       const bool go = verifying && best < lim;
+      // the nearest mask register that still has candidates, and the next one: a lane whose nearest register holds fewer
+      // than LZ_POP goes on in the next (still nearest first), so that a step's few candidates rarely need a second pass
       const uint32_t r32 = cm[4] != 0u ? 128u : cm[3] != 0u ? 96u : cm[2] != 0u ? 64u : cm[1] != 0u ? 32u : 0u; // 32 * the register
       uint32_t m = cm[4] != 0u ? cm[4] : cm[3] != 0u ? cm[3] : cm[2] != 0u ? cm[2] : cm[1] != 0u ? cm[1] : cm[0];
+      const uint32_t s32 = (r32 > 96u && cm[3] != 0u) ? 96u : (r32 > 64u && cm[2] != 0u) ? 64u : (r32 > 32u && cm[1] != 0u) ? 32u : 0u;
+      uint32_t m2 = r32 == 0u ? 0u : (s32 == 96u ? cm[3] : s32 == 64u ? cm[2] : s32 == 32u ? cm[1] : cm[0]);
       m = go ? m : 0u;
+      m2 = go ? m2 : 0u;
       uint32_t qb[LZ_POP], e[LZ_POP][3];
       uint32_t has = 0;
 #pragma unroll
       for (uint32_t k = 0; k < LZ_POP; k++)
       {
-        has |= m != 0 ? 1u << k : 0u;
-        const uint32_t bit = 31u - clz32(m | 1u);
-        m &= ~(1u << bit);
-        qb[k] = 4u * wd0 + r32 + bit; // window byte index of the candidate (a valid address also when there is none)
+        const bool first = m != 0u;
+        const uint32_t mm = first ? m : m2;
+        has |= mm != 0 ? 1u << k : 0u;
+        const uint32_t bit = 31u - clz32(mm | 1u);
+        const uint32_t left = mm & ~(1u << bit);
+        m = first ? left : m;
+        m2 = first ? m2 : left;
+        qb[k] = 4u * wd0 + (first ? r32 : s32) + bit; // window byte index of the candidate (a valid address also when there is none)
         const uint32_t qd = qb[k] >> 2;
 #pragma unroll
         for (uint32_t j = 0; j < 3; j++)
@@ -389,10 +398,10 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
       if (go)
       {
         cm[4] = r32 == 128u ? m : cm[4];
-        cm[3] = r32 == 96u ? m : cm[3];
-        cm[2] = r32 == 64u ? m : cm[2];
-        cm[1] = r32 == 32u ? m : cm[1];
-        cm[0] = r32 == 0u ? m : cm[0];
+        cm[3] = r32 == 96u ? m : (s32 == 96u && r32 > 96u) ? m2 : cm[3];
+        cm[2] = r32 == 64u ? m : (s32 == 64u && r32 > 64u) ? m2 : cm[2];
+        cm[1] = r32 == 32u ? m : (s32 == 32u && r32 > 32u) ? m2 : cm[1];
+        cm[0] = r32 == 0u ? m : (s32 == 0u && r32 > 0u) ? m2 : cm[0];
       }
       // first the leading 8 bytes of every candidate (3 window dwords each): all that 97 % of them have to show
       uint32_t len[LZ_POP];
