@@ -281,15 +281,15 @@ template <bool AD, bool NARROW, bool F32>
 static void encode_launch(bool wide, size_t C, hipStream_t s, const EncodeArgs &a)
 {
   if (wide) // more channels than one coding wave per SIMD: 8 pairs of waves per workgroup, smaller rings
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 4, 16, 24, false, F32, 8>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 4, 16, 8, 16, false, F32, 8, false>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
   else
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_RAW, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
                        dim3(ENC_BLOCK), 0, s, a);
 }
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
 static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_t batch_C, uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err,
-                         hipStream_t s, const uint32_t *rows_ready = nullptr)
+                         hipStream_t s, uint32_t *seg_state = nullptr, uint32_t seg_flags = 0)
 {
   int ret;
   if ((ret = check_job_shape(ctx, j, cap)) != DEGA_OK)
@@ -311,7 +311,8 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
   a.valuesize = (uint32_t)vs;
   a.big_endian = j.samples == DEGA_SAMPLES_BE32 ? 1u : 0u;
   a.factor = j.factor;
-  a.rows_ready = rows_ready;
+  a.seg_state = seg_state;
+  a.seg_flags = seg_flags;
   // the bounds of normalize.c:21, rounded to float by the host compiler exactly as the reference's are
   a.lo = -(float)((uint64_t)1 << (vs - 1));
   a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);
@@ -325,14 +326,14 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
       if (f32)
       {
         if (ad)
-          hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 16, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
         else
-          hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
+          hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 16, 32, true, true>), grid, dim3(ENC_BLOCK), 0, s, a);
       }
       else if (ad)
-        hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_encode_kernel<true, false, 4, 32, 16, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
       else
-        hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((dega_encode_kernel<false, false, 4, 32, 16, 32, true, false>), grid, dim3(ENC_BLOCK), 0, s, a);
     }
     else
     {

@@ -64,14 +64,21 @@ DG_DEV float denormalize_value(float n, float factor) // normalize.c:38: true IE
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
 
-constexpr uint32_t ENC_RING = 32;                               // queued words per lane (LDS: 4 KiB per wave)
+constexpr uint32_t ENC_RING = 32;                               // queued words per lane (LDS: 8 KiB per pair)
 constexpr uint32_t ENC_ROWS = 8;                                // rows per fill batch
 constexpr uint32_t ENC_FILL_WORDS = (31 + 65 * ENC_ROWS) / 32;  // most words a batch can add (65-bit worst-case codewords)
 static_assert(ENC_FILL_WORDS < ENC_RING, "ring too small");
 
+// A channel can be coded over several launches, each taking the next range of rows (the host pipeline uploads a batch of
+// few, long channels in bands and codes every band as it lands; a stream longer than one call's 2^25 samples): the state
+// of a lane's three state machines between two launches, ENC_STATE_WORDS dwords per channel, [word][channel].
+constexpr uint32_t ENC_STATE_WORDS = 18;
+constexpr uint32_t ENC_SEG_CONTINUES = 1; // the launch goes on from saved state
+constexpr uint32_t ENC_SEG_MORE = 2;      // more rows follow in a later launch: no EOF symbol, state saved
+
 struct EncodeArgs
 {
-  const int32_t *x; // [T][ld]
+  const int32_t *x; // [T][ld]: the rows of this launch
   size_t C, T, ld;
   uint8_t *out;     // [C][cap]
   size_t cap;       // bytes per channel, multiple of 4
@@ -82,9 +89,8 @@ struct EncodeArgs
   uint32_t big_endian;       // 32-bit samples arrive byte swapped (the big-endian words `encode normalize` writes, bit_file_buffer.c:297-308)
   // F32IN variants (normalize fused into the fill phase, normalize.c:9-27): x holds raw float32 bits
   float factor, lo, hi;      // normalization factor; range of normalize.c:21 for the value size, rounded to float by the host compiler
-  // NULL: every row of x is there when the kernel starts.  Else: rows [0, *rows_ready) are -- the host pipeline uploads a
-  // batch of few, long channels in bands of rows while the kernel already codes (the word grows; dega_pipeline.hpp)
-  const uint32_t *rows_ready;
+  uint32_t *seg_state;       // NULL: whole channels in one launch.  Else [ENC_STATE_WORDS][C], see above
+  uint32_t seg_flags;        // ENC_SEG_*
 };
 
 // `symbols`: no channel of the batch codes more symbols than this (cum[0] starts at 3 and grows by one per symbol until
@@ -94,7 +100,7 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 {
   if (ADAPTIVE)
   {
-    const uint32_t words = symbols + 68u < DIV_TABLE_SIZE ? (uint32_t)symbols + 68u : DIV_TABLE_SIZE; // + the fetch-ahead of a word
+    const uint32_t words = symbols < DIV_TABLE_SIZE - 68u ? (uint32_t)symbols + 68u : DIV_TABLE_SIZE; // + the fetch-ahead of a word
     for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
       tab[i] = gtab[i];
   }
@@ -103,31 +109,40 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
   __syncthreads();
 }
 
-// One workgroup = ENC_PAIRS pairs of waves = ENC_CHANNELS channels.  Of each pair (wave p and wave p + 4: the CU deals a
-// workgroup's waves out to its four SIMDs in turn, so the two share a SIMD) the first FILLS -- rows in, seg bits into the
-// lane's column of an LDS ring -- and the second CODES: ring words through the arithmetic coder, coded words to the slab.
-// A channel's coder is serial and instruction bound, and 64 Ki channels are only one coding wave per SIMD: with the row
-// traffic, the row lockstep and their waits in a wave of their own, the coding wave does nothing but code, and whatever
-// it still waits for, the filling wave's instructions go into.  The two talk through one published word per lane and
-// direction (counters modulo 2^16, peer_store / peer_load); a wave with nothing to do sleeps.
-//   filler publishes: ring words written (mod 2^16) | bits of the final, partial word << 16 | all rows done << 24 |
-//                     a value was out of range << 25 | the rows stopped arriving (rows_ready) << 26
-//   coder publishes:  ring words consumed (mod 2^16)
-// ROWS rows per fill batch, RING / ORING words of seg-bit / output ring per lane.
+// One workgroup = PAIRS pairs of waves = PAIRS * 64 channels.  Of each pair (wave p and wave p + PAIRS: the CU deals a
+// workgroup's waves out to its four SIMDs in turn, so the two share a SIMD) the second CODES -- seg-bit words through the
+// arithmetic coder, nothing else -- and the first HELPS: it fills (rows in, normalize, diff, seg -> bit words into the
+// lane's column of an LDS ring) and it writes (the coder's raw entries -> 32-bit words -> the slab).
+// A channel's coder is serial and bound by the instructions of ITS wave: one wave issues an instruction every 4.1 - 4.6
+// cycles whatever shares the SIMD with it, while two waves together get ~3.2 cycles per instruction out of the SIMD and
+// four ~2.5 (profiles/r03_ubench2_issue_cost.txt).  64 Ki channels are one coding wave per SIMD: every instruction that is
+// not the arithmetic itself is worth moving into the partner, whose instructions go into issue slots the coder cannot use.
+// The two talk through one published word per lane and direction (peer_store / peer_load); a wave with nothing to do sleeps.
+//   helper publishes: ring words written (mod 2^16) | raw entries absorbed (mod 2^8) << 16 | all rows done << 24 |
+//                     bits of the final, partial word << 27
+//   coder publishes:  ring words consumed (mod 2^16) | raw entries written (mod 2^8) << 16 | all entries written << 24
+// ROWS rows per fill batch; RING / RAW / ORING: seg-bit words, raw entries, staged output words per lane.
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
 // writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated with ROWS = 4.
 // F32IN: the rows are float32 readings; Normalize (normalize.c:16-24) runs on each value as it leaves LDS, in front of
 // the difference -- one launch, no int32 intermediate in HBM.  With W64 the rows stay one dword per lane (floats) and
 // the normalized value is 64 bits wide (valuesize 33..64, normalize.c:21-24 with io_int_t = int64).
 // How the two waves of a pair share their SIMD: how long a wave with nothing to do sleeps (units of 64 cycles) and the
-// issue priority of the coding waves.  Compile-time, so that tools/tunebench.py can time variants side by side; measured
-// on the probe batch: priority 3 for the encoder's coding wave -10 %, no effect in the decoder (its pair is bound by the
-// sum of both waves' instructions), sleeps of 2 .. 16 no effect, 32 and more slower.
+// issue priority of the coding waves.  Compile-time, so that tools/tunebench.py can time variants side by side.
 #ifndef DG_ENC_FILL_SLEEP
-#define DG_ENC_FILL_SLEEP 2
+#define DG_ENC_FILL_SLEEP 12
+#endif
+#ifndef DG_ENC_WRITE_SLEEP
+#define DG_ENC_WRITE_SLEEP 6
 #endif
 #ifndef DG_ENC_CODE_SLEEP
 #define DG_ENC_CODE_SLEEP 1
+#endif
+#ifndef DG_ENC_FILL_PRIO
+#define DG_ENC_FILL_PRIO 0
+#endif
+#ifndef DG_ENC_WRITE_PRIO
+#define DG_ENC_WRITE_PRIO 1
 #endif
 #ifndef DG_ENC_CODE_PRIO
 #define DG_ENC_CODE_PRIO 3
@@ -145,27 +160,52 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 #define DG_DEC_TAKES 4
 #endif
 constexpr uint32_t ENC_PAIRS = 4;
-constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 128;   // threads per workgroup
+constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 192;   // threads per workgroup (narrow batches: a filling, a coding and a writing wave per 64 channels)
 constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
-constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25, ENC_PUB_LOST = 1u << 26;
-constexpr uint32_t ENC_ROWS_POLLS = 1u << 20; // polls of rows_ready (2 - 3 microseconds each) before a wave gives the upload up
+constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25;
 
-// ---- the filling wave ------------------------------------------------------------------------------------------------
-template <bool NARROW, uint32_t ROWS, uint32_t RING, bool W64, bool F32IN>
-DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_t *rows_wave, uint32_t *pub_mine, const uint32_t *pub_peer, uint32_t lane,
-                                size_t c, bool live, size_t c_wave0)
+// ---- the helping wave(s): fill and write -------------------------------------------------------------------------------
+// FILLS / WRITES: both in one wave (batches of more than 64 Ki channels: two coding waves per SIMD cover for each other
+// when a helper is late), or a wave each (up to 64 Ki channels: the one coding wave of a SIMD must never wait, and three
+// waves get more instructions per cycle out of a SIMD than two).
+template <bool NARROW, uint32_t ROWS, uint32_t RING, uint32_t RAW, uint32_t ORING, bool W64, bool F32IN, bool FILLS, bool WRITES>
+DG_DEV void encode_helping_wave(const EncodeArgs &a, uint32_t *ring_col, const uint32_t *raw_col, uint32_t *oring_col, uint32_t *rows_wave, uint32_t *pub_mine,
+                                const uint32_t *pub_peer, uint32_t lane, size_t c, bool live, size_t c_wave0)
 {
+  static_assert(FILLS || WRITES, "a helper with nothing to do");
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
   constexpr uint32_t FILL_WORDS = (31 + (W64 ? 127 : 65) * ROWS) / 32; // most words a batch can add (worst-case codewords)
   constexpr bool ROWS64 = W64 && !F32IN; // rows of two dwords per lane
+  constexpr uint32_t GROUP = ORING / 2;  // staged words stored together: 64 bytes for the narrow batches' 32-word staging ring
   static_assert(FILL_WORDS < RING, "ring too small");
+  static_assert(GROUP % 4 == 0 && GROUP >= 4, "whole 16-byte stores");
   const uint32_t vmask = NARROW ? (1u << (a.valuesize & 31u)) - 1u : 0xFFFFFFFFu, vhalf = NARROW ? 1u << ((a.valuesize - 1u) & 31u) : 0x80000000u;
+  const bool continues = a.seg_state != nullptr && (a.seg_flags & ENC_SEG_CONTINUES) != 0u;
+  const bool more = a.seg_state != nullptr && (a.seg_flags & ENC_SEG_MORE) != 0u;
+  uint32_t *const state = a.seg_state != nullptr && live ? a.seg_state + c : nullptr; // word k at state[k * C]
 
   BitQueue q;
   q.init();
   uint32_t last = 0; // diff.c:11
   uint64_t last64 = 0;
   int32_t lane_err = OK;
+  BacWriter<ORING> wr;
+  wr.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u, oring_col);
+  if (continues && live)
+  {
+    q.acc = ((uint64_t)state[1 * a.C] << 32) | state[0];
+    q.cnt = state[2 * a.C];
+    last = state[3 * a.C];
+    last64 = ((uint64_t)state[4 * a.C] << 32) | last;
+    lane_err = (int32_t)state[5 * a.C];
+    wr.err = (int32_t)state[16 * a.C];
+    wr.F = ((uint64_t)state[7 * a.C] << 32) | state[6 * a.C];
+    wr.fcnt = state[8 * a.C];
+    wr.prev = state[9 * a.C];
+    wr.pos = state[10 * a.C];
+    wr.drained = wr.pos > 0u ? wr.pos - 1u : 0u; // everything but the held-back word is in the slab
+  }
+  uint32_t rrd = 0; // raw entries absorbed
 
   // Input rows travel HBM -> LDS directly (LDS-DMA, `global_load_lds_dword`: one 256-byte row segment per wave
   // instruction, no VGPR destination) and are read from LDS by the next fill; the next batch is requested right after a
@@ -218,42 +258,9 @@ DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_
       rowp += a.ld;
     }
   };
-  // rows that are in device memory (all of them unless the host pipeline is still uploading: EncodeArgs::rows_ready)
-  uint32_t rows_there = a.rows_ready == nullptr ? 0xFFFFFFFFu : 0u;
-  bool lost = false;
-  auto await_rows = [&](size_t upto) // rows [0, min(upto, T)) are there; false: given up
-  {
-    const uint32_t want = (uint32_t)(upto < a.T ? upto : a.T);
-    for (uint32_t polls = 0; rows_there < want; polls++)
-    {
-      rows_there = wave_uniform(load_written_by_host(a.rows_ready));
-      if (rows_there >= want)
-        break;
-      if (polls >= ENC_ROWS_POLLS)
-        return false;
-      wave_sleep<16>();
-    }
-    return true;
-  };
-  if (a.T > 0)
-  {
-    if (await_rows(ROWS))
-      issue_rows(0);
-    else
-      lost = true;
-  }
 
-  while (t < a.T && !lost)
-  {
-    // ---- the same ROWS rows for every lane, as soon as every lane's ring has room for what they may add ---------------
-    const uint32_t taken = peer_load(pub_peer);
-    const bool room = ((q.wr - taken) & 0xFFFFu) + FILL_WORDS <= RING;
-    if (!wave_all(room))
-    {
-      wave_sleep<DG_ENC_FILL_SLEEP>();
-      continue;
-    }
-    wait_vector_memory();
+  // ---- one batch of ROWS rows (or what is left of them) into the lanes' bit queues -------------------------------------------
+  auto fill_batch = [&]() {
     const size_t left = a.T - t;
     if constexpr (W64)
     {
@@ -360,85 +367,299 @@ DG_DEV void encode_filling_wave(const EncodeArgs &a, uint32_t *ring_col, uint32_
       }
     }
     t += left < ROWS ? left : ROWS;
-    peer_store(pub_mine, q.wr & 0xFFFFu);
-    if (t < a.T)
+  };
+
+  wave_priority<(FILLS ? DG_ENC_FILL_PRIO : DG_ENC_WRITE_PRIO)>();
+  if (FILLS && a.T > 0)
+    issue_rows(0);
+  bool tail_placed = !FILLS; // the final, partial word is in the ring (or stays in the state) and "done" is published
+  uint32_t pub_flags = 0;
+  for (;;)
+  {
+    const uint32_t cp = peer_load(pub_peer);
+    bool worked = false;
+    // ---- fill: the same ROWS rows for every lane, as soon as every lane's ring has room for what they may add -----------
+    if (FILLS && t < a.T)
     {
-      if (await_rows(t + ROWS))
-        issue_rows(t); // in flight while the coder works through this batch
-      else
-        lost = true;
+      const bool room = ((q.wr - cp) & 0xFFFFu) + FILL_WORDS <= RING;
+      if (wave_all(room))
+      {
+        wait_vector_memory();
+        fill_batch();
+        if (t < a.T)
+          issue_rows(t); // in flight while the coder works through this batch
+        worked = true;
+      }
+    }
+    // The last, partial word of the seg stream goes into the next ring slot, left aligned -- once that slot is free: a
+    // batch of worst-case codewords can leave the ring full to the last slot (RING words queued), and the next slot is
+    // then the oldest word the coder has not taken yet.  When more rows follow in a later launch the bits stay in the
+    // queue (saved with the state) and the coder gets no partial word.
+    if (FILLS && t >= a.T && !tail_placed && !wave_any(((q.wr - cp) & 0xFFFFu) >= RING))
+    {
+      uint32_t tail_bits = 0;
+      if (!more)
+      {
+        ring_col[(q.wr % RING) * 64u] = q.cnt != 0u ? (uint32_t)(q.acc << (32u - q.cnt)) : 0u;
+        tail_bits = q.cnt;
+      }
+      pub_flags = ENC_PUB_DONE | (tail_bits << 27) | (lane_err != OK ? ENC_PUB_BAD : 0u);
+      tail_placed = true;
+      worked = true;
+    }
+    // ---- write: the coder's raw entries, oldest first, all lanes in step ---------------------------------------------------
+    uint32_t avail = WRITES ? ((cp >> 16) - rrd) & 0xFFu : 0u;
+    if (WRITES && wave_any(avail != 0u))
+    {
+      uint32_t budget = GROUP; // entries per pass: the staging ring takes a group's worth on top of what waits to be stored
+      // The steady state: every lane has the four entries of a fast word step, a word held back, and room in F for all
+      // four -- one address, four reads in flight, straight-line code for all 64 lanes, one hand-over.
+      if (wave_all(avail >= 4u && wr.pos != 0u))
+      {
+        const uint32_t *const slot = raw_col + (rrd % RAW) * 64u;
+        uint32_t hi[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+          hi[k] = slot[k * 64u];
+        if (wave_all(wr.fits4(hi)))
+        {
+          const bool rippled = wr.absorb4_in_step(hi);
+          if (wave_any(rippled))
+          {
+            if (rippled)
+              wr.ripple_carry_from(wr.pos - 2u);
+          }
+          rrd += 4u;
+          avail -= 4u;
+          budget -= 4u;
+        }
+      }
+      // the four entries of a fast word step together (the entry count stays a multiple of 4 until the stream ends:
+      // BacCoder::end_bits_word): one address, four reads in flight, one hand-over
+      while (budget >= 4u && wave_any(avail >= 4u))
+      {
+        const bool four = avail >= 4u;
+        const uint32_t *const slot = raw_col + (rrd % RAW) * 64u;
+        uint32_t hi[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+          hi[k] = four ? slot[(k % RAW) * 64u] : 2u;
+        if (!wave_any(four && !wr.fits4(hi)))
+        {
+          if (four)
+            wr.absorb4(hi);
+        }
+        else if (four)
+        {
+#pragma unroll 1
+          for (uint32_t k = 0; k < 4; k++)
+            wr.absorb(hi[k]);
+        }
+        rrd += four ? 4u : 0u;
+        avail -= four ? 4u : 0u;
+        budget -= 4u;
+      }
+      while (budget != 0u && wave_any(avail != 0u && avail < 4u)) // the last entries of a stream
+      {
+        if (avail != 0u && avail < 4u)
+        {
+          wr.absorb(raw_col[(rrd % RAW) * 64u]);
+          rrd++;
+          avail--;
+        }
+        budget--;
+      }
+      // whole groups of staged words -> the slab: consecutive 16-byte stores, so that a lane's stores fill whole 64-byte
+      // segments of its slab (16-byte stores scattered in time left 128-byte lines half written: 1.6 x the stream bytes
+      // went to HBM)
+      while (wave_any(wr.staged >= GROUP))
+      {
+        if (wr.staged >= GROUP)
+        {
+          uint32_t g[GROUP];
+#pragma unroll
+          for (uint32_t k = 0; k < GROUP; k++)
+            g[k] = wr.oring[((wr.drained + k) % ORING) * 64u];
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 1)
+          if (g[0] == 0x12345u) // diagnostic build: no output stores
+#endif
+          {
+#pragma unroll
+            for (uint32_t k = 0; k < GROUP; k += 4)
+              wr.put_group(wr.drained + k, g[k], g[k + 1], g[k + 2], g[k + 3]);
+          }
+          wr.drained += GROUP;
+          wr.staged -= GROUP;
+        }
+      }
+      worked = true;
+    }
+    peer_store(pub_mine, (q.wr & 0xFFFFu) | ((rrd & 0xFFu) << 16) | pub_flags);
+    // through: the tail is placed (filling), the coder has written its last entry and every entry is absorbed (writing)
+    if (tail_placed && (!WRITES || wave_all((cp & ENC_PUB_DONE) != 0u && (((cp >> 16) - rrd) & 0xFFu) == 0u)))
+      break;
+    if (!worked)
+      wave_sleep<(WRITES ? DG_ENC_WRITE_SLEEP : DG_ENC_FILL_SLEEP)>(); // (a poll costs a dozen instructions of a SIMD that has none to spare)
+  }
+  if (FILLS)
+    wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
+  if (!live)
+    return;
+  if (more)
+  {
+    // the state machines' registers to the state (the coder saves its own); everything but the held-back word to the slab
+    if (FILLS)
+    {
+      state[0] = (uint32_t)q.acc;
+      state[1 * a.C] = (uint32_t)(q.acc >> 32);
+      state[2 * a.C] = q.cnt;
+      state[3 * a.C] = W64 ? (uint32_t)last64 : last;
+      state[4 * a.C] = (uint32_t)(last64 >> 32);
+      state[5 * a.C] = (uint32_t)lane_err;
+    }
+    if (WRITES)
+    {
+      wr.drain_lane();
+      state[6 * a.C] = (uint32_t)wr.F;
+      state[7 * a.C] = (uint32_t)(wr.F >> 32);
+      state[8 * a.C] = wr.fcnt;
+      state[9 * a.C] = wr.prev;
+      state[10 * a.C] = wr.pos;
+      state[16 * a.C] = (uint32_t)wr.err;
     }
   }
-  // the last, partial word of the seg stream goes into the next ring slot, left aligned -- once that slot is free: a
-  // batch of worst-case codewords can leave the ring full to the last slot (RING words queued), and the next slot is
-  // then the oldest word the coder has not taken yet
-  while (wave_any(((q.wr - peer_load(pub_peer)) & 0xFFFFu) >= RING))
-    wave_sleep<DG_ENC_FILL_SLEEP>();
-  ring_col[(q.wr % RING) * 64u] = q.cnt != 0u ? (uint32_t)(q.acc << (32u - q.cnt)) : 0u;
-  peer_store(pub_mine, (q.wr & 0xFFFFu) | (q.cnt << 16) | ENC_PUB_DONE | (lane_err != OK ? ENC_PUB_BAD : 0u) | (lost ? ENC_PUB_LOST : 0u));
+  else
+  {
+    // the last launch of a channel: the writer reports its length and the verdict -- a value out of range (the filler's
+    // finding: diff.c:17-18, normalize.c:21; a filler in a wave of its own publishes it with "done" and the coder hands
+    // it on with its own) before a slab too small
+    if (WRITES)
+    {
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+      (void)wr.finish();
+#else
+      a.out_bits[c] = wr.finish();
+#endif
+      const bool bad_value = FILLS ? lane_err != OK : (peer_load(pub_peer) & ENC_PUB_BAD) != 0u;
+      a.err[c] = bad_value ? ERR_INVALID_VALUE : wr.err;
+    }
+  }
 }
 
 // ---- the coding wave -------------------------------------------------------------------------------------------------
-template <bool ADAPTIVE, uint32_t RING, uint32_t ORING>
-DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const uint32_t *ring_col, uint32_t *oring_col, uint32_t *pub_mine,
-                               const uint32_t *pub_peer, uint32_t lane, size_t c, bool live)
+// SPLIT: filler and writer are two waves with a published word each (else: one wave, one word)
+template <bool ADAPTIVE, uint32_t RING, uint32_t RAW, bool SPLIT>
+DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const uint32_t *ring_col, uint32_t *raw_col, uint32_t *pub_mine, const uint32_t *pub_peer,
+                               const uint32_t *pub_writer, uint32_t lane, size_t c, bool live)
 {
-  BacEncoder<ADAPTIVE, ORING> enc;
-  enc.init(live ? reinterpret_cast<uint32_t *>(a.out + c * a.cap) : nullptr, live ? (uint32_t)(a.cap / 4) : 0u, oring_col);
+  BacCoder<ADAPTIVE, RAW> enc;
+  enc.init(raw_col, pub_writer);
+  const bool continues = a.seg_state != nullptr && (a.seg_flags & ENC_SEG_CONTINUES) != 0u;
+  const bool more = a.seg_state != nullptr && (a.seg_flags & ENC_SEG_MORE) != 0u;
+  uint32_t *const state = a.seg_state != nullptr && live ? a.seg_state + c : nullptr;
+  if (continues && live)
+  {
+    enc.L = ((uint64_t)2 << 32) | state[11 * a.C];
+    enc.B = state[12 * a.C];
+    enc.c1 = state[13 * a.C];
+    enc.tot = state[14 * a.C];
+    enc.mps = state[15 * a.C];
+  }
   uint32_t rd = 0; // ring words coded so far
-  // The filler's count as read one step ago: a word may only be read after a count that covers it, and waiting for the
-  // count before asking for the word would put two LDS round trips at the head of every step.  One step late costs
-  // nothing (the count only grows, the ring holds a dozen words).
-  uint32_t peer = peer_load(pub_peer);
+  // The helper's word as read one step ago: a ring word may only be read after a count that covers it, and waiting for
+  // the count before asking for the word would put two LDS round trips at the head of every step.  One step late costs
+  // nothing (the counts only grow, the ring holds a dozen words).
+  uint32_t peer = peer_load(pub_peer), peerw = SPLIT ? peer_load(pub_writer) : peer;
+  enc.classify(); // the class of the first word
   wave_priority<DG_ENC_CODE_PRIO>();
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+  // diagnostic build: what the coding wave's passes were (steady / steady masked / other word paths / nothing to do: no word, no room), in cycles too
+  uint64_t dg_n[4] = {0, 0, 0, 0}, dg_c[4] = {0, 0, 0, 0}, dg_t = __builtin_amdgcn_s_memtime();
+#define DG_COUNT(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); dg_n[k]++; dg_c[k] += now_ - dg_t; dg_t = now_; } while (0)
+#else
+#define DG_COUNT(k)
+#endif
 
-  DG_STAMP_DECL;
   for (;;)
   {
-    DG_STAMP(7);
     // ---- one queued word (32 symbols) for every lane that has one ------------------------------------------------------
-    // What a code step reads from LDS first -- the filler's count, the queued word and the first quarter of its division
+    // What a code step reads from LDS first -- the helper's word, the queued word and the first quarter of its division
     // magics -- is asked for here, ahead of the ballots that choose the word path; nothing LDS is carried around the loop
     // (a wait at the back edge would be a wait for the whole queue).
     const bool has = ((peer - rd) & 0xFFFFu) != 0u;
     const bool all_done = (peer & ENC_PUB_DONE) != 0u;
+    const bool room4 = enc.raw_room(enc.rwr, peerw, 4u), room8 = enc.raw_room(enc.rwr, peerw, 8u);
     const uint32_t word = ring_col[(rd % RING) * 64u];
     uint32_t Mg[32];
     enc.fetch_magics_first(tab, Mg);
     peer = peer_load(pub_peer);
-    const bool any_has = wave_any(has);
-    DG_STAMP(2);
-    if (!any_has)
+    peerw = SPLIT ? peer_load(pub_writer) : peer;
+    // The steady state: every lane of the wave has a word, room for its four entries, and a fast class (every lane knows the
+    // class of its NEXT word and for how many words it holds: BacCoder::classify, looked at again when the count has run out,
+    // at the end of the step) -- one ballot, then straight-line code for all 64 lanes, no exec masks, no merges.
+    const bool ready = has && room4;
+    if (wave_all(ready && enc.cls == CLS_FAST8))
     {
-      if (wave_all(all_done))
-        break; // all rows consumed and every queue drained ("done" comes in one word with the final count)
-      wave_sleep<DG_ENC_CODE_SLEEP>();
+      enc.template encode_word<false, 8>(word, tab, Mg);
+      rd++;
+      enc.safe--;
+      if (wave_any(enc.safe == 0u))
+      {
+        if (enc.safe == 0u)
+          enc.classify();
+      }
+      peer_store(pub_mine, (rd & 0xFFFFu) | ((enc.rwr & 0xFFu) << 16));
+      DG_COUNT(0);
       continue;
     }
-    // Which word path?  Every lane knows the class of its next word and for how many words that class still holds
-    // (BacEncoder::classify: looked at again only when the count has run out); the wave takes the most expensive
-    // class among its lanes.  In the steady state this is one ballot.
-    if (wave_any(has && enc.safe == 0u && enc.part_lo == 0u))
+    // The same with some lanes at a halving of the counts or a change of the division shift (CLS_SPLIT: the word in two
+    // parts, see BacCoder): the masked fast path for all 64 lanes -- whole words for the others
+    if constexpr (ADAPTIVE)
     {
-      if (has && enc.safe == 0u && enc.part_lo == 0u)
-        enc.classify();
+      if (wave_all(ready && enc.cls <= CLS_SPLIT))
+      {
+        enc.template encode_word<false, 8, true>(word, tab, Mg);
+        const bool whole = enc.cls != CLS_SPLIT || enc.after_part(word);
+        rd += whole ? 1u : 0u;
+        enc.safe -= enc.safe != 0u ? 1u : 0u;
+        const bool again = whole && enc.safe == 0u;
+        if (wave_any(again))
+        {
+          if (again)
+            enc.classify();
+        }
+        peer_store(pub_mine, (rd & 0xFFFFu) | ((enc.rwr & 0xFFu) << 16));
+        DG_COUNT(1);
+        continue;
+      }
     }
-    uint32_t cls = has ? enc.cls : CLS_FAST8;
-    bool act = has; // lanes that code (a part of) a word in this step
-    uint32_t record = 0, groups = 4; // a carry past the held-back word, recorded by the word path (see settle_ripples)
+    // (the slower word paths write eight entries; the bit path waits for room by itself).  A lane with a word but no room
+    // for its entries holds the whole wave up: the writer never waits for this wave, so room comes, and the lanes stay in
+    // step -- a wave whose lanes take turns needs more steps, each with its exec masks and merges
+    const bool can = has && room8;
+    if (!wave_any(can) || wave_any(has && !room8))
+    {
+      if (wave_all(all_done && !has))
+        break; // all rows consumed and every queue drained ("done" comes in one word with the final count)
+      wave_sleep<DG_ENC_CODE_SLEEP>();
+      DG_COUNT(3);
+      continue;
+    }
+    // Which word path?  The wave takes the most expensive class among its lanes.
+    uint32_t cls = can ? enc.cls : CLS_FAST8;
+    bool act = can; // lanes that code (a part of) a word in this step
     if (!wave_any(cls != CLS_FAST8))
     {
-      if (has)
-        record = enc.template encode_word<false, 8>(word, tab, Mg);
-      DG_STAMP(3);
+      if (can)
+        enc.template encode_word<false, 8>(word, tab, Mg);
     }
     else
     {
       // A lane in the middle of a halving word (CLS_SPLIT, second part) needs the masked fast path: lanes that need a
       // slower one sit this step out.  A halving word not yet begun goes whole through the general path when the
       // wave takes that one anyway.
-      if (wave_any(has && enc.part_lo != 0u))
-        act = has && cls <= CLS_SPLIT;
+      if (wave_any(can && enc.part_lo != 0u))
+        act = can && cls <= CLS_SPLIT;
       else if (wave_any(cls > CLS_SPLIT))
       {
         if (cls == CLS_SPLIT)
@@ -452,130 +673,83 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
         if constexpr (ADAPTIVE)
         {
           if (act)
-            record = enc.template encode_word<false, 8, true>(word, tab, Mg);
+            enc.template encode_word<false, 8, true>(word, tab, Mg);
         }
-        DG_STAMP(4);
       }
       else
       {
         const bool any_bits = wave_any(cls == CLS_BITS), any_general = wave_any(cls == CLS_GENERAL);
-        groups = 8;
-        if (has)
+        if (can)
         {
           if (any_bits)
           {
 #pragma unroll 1
             for (uint32_t i = 0; i < 32; i++)
               enc.encode_bit((word >> (31u - i)) & 1u, tab);
+            enc.end_bits_word();
           }
           else if (any_general)
           {
             if constexpr (ADAPTIVE)
-              record = enc.template encode_word<true, 4>(word, tab, Mg);
+              enc.template encode_word<true, 4>(word, tab, Mg);
           }
           else
-            record = enc.template encode_word<false, 4>(word, tab, Mg);
+            enc.template encode_word<false, 4>(word, tab, Mg);
         }
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-        if (any_bits)
-          DG_STAMP(5);
-        else
-          DG_STAMP(1);
-#endif
       }
-    }
-    if (wave_any(record != 0u)) // once in 2^32 hand-overs of random data
-    {
-      if (record != 0u)
-        enc.settle_word(record, groups);
     }
     if (act)
     {
       const bool whole = enc.cls != CLS_SPLIT || cls != CLS_SPLIT || enc.after_part(word);
       rd += whole ? 1u : 0u;
       enc.safe -= enc.safe != 0u ? 1u : 0u;
+      if (whole && enc.safe == 0u)
+        enc.classify(); // the class of the next word
     }
-    peer_store(pub_mine, rd & 0xFFFFu);
-    DG_STAMP(0);
-    // ---- drain: staged words -> slabs, all lanes in lockstep -----------------------------------------------------------
-    // As soon as some column could not take another word path's worth of output, every lane that holds a whole 64-byte
-    // group stores it: four 16-byte stores to consecutive addresses, so a lane's stores fill whole 64-byte segments of
-    // its slab (16-byte stores scattered in time left 128-byte lines half written: 1.6 x the stream bytes went to HBM).
-    if (wave_any(enc.staged + ENC_WORD_MAX_OUT > ORING))
-    {
-      constexpr uint32_t GROUP = 16;
-      uint32_t base = 0; // first staged slot not yet stored
-      while (wave_any(enc.staged - base >= GROUP))
-      {
-        if (enc.staged - base >= GROUP)
-        {
-          const uint32_t *const sl = enc.oring + base * 64u;
-          uint32_t g[GROUP];
-#pragma unroll
-          for (uint32_t k = 0; k < GROUP; k++)
-            g[k] = sl[k * 64u];
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 1)
-          if (g[0] == 0x12345u) // diagnostic build: no output stores
-#endif
-          {
-#pragma unroll
-            for (uint32_t k = 0; k < GROUP; k += 4)
-              enc.put_group(enc.drained + base + k, g[k], g[k + 1], g[k + 2], g[k + 3]);
-          }
-          base += GROUP;
-        }
-      }
-      // move the left-over words (fewer than a group) to the front of the column
-      const uint32_t rest = enc.staged - base;
-      if (base > 0)
-      {
-        const uint32_t *const sl = enc.oring + base * 64u;
-        uint32_t g[GROUP - 1];
-#pragma unroll
-        for (uint32_t k = 0; k < GROUP - 1; k++)
-          g[k] = sl[(k < ORING - GROUP ? k : 0u) * 64u]; // at most ORING - GROUP words can be left over
-#pragma unroll
-        for (uint32_t k = 0; k < GROUP - 1 && k < ORING - GROUP; k++)
-          if (k < rest)
-            enc.oring[k * 64u] = g[k];
-      }
-      enc.drained += base;
-      enc.staged = rest;
-    }
-    DG_STAMP(6);
+    peer_store(pub_mine, (rd & 0xFFFFu) | ((enc.rwr & 0xFFu) << 16));
+    DG_COUNT(2);
   }
 
   if (live)
   {
-    // the last, partial word of the seg stream (left aligned in the filler's next ring slot), then EOF + flush (bac.c:163-164)
-    const uint32_t tail = (peer >> 16) & 31u;
+    // the last, partial word of the seg stream (left aligned in the helper's next ring slot), then EOF + flush
+    // (bac.c:163-164) -- or, when more rows follow in a later launch, nothing but a last dump: the state keeps A only
+    const uint32_t tail = peer >> 27;
     const uint32_t tword = ring_col[(rd % RING) * 64u];
     for (uint32_t i = 0; i < tail; i++)
       enc.encode_bit((tword >> (31u - i)) & 1u, tab);
-    a.out_bits[c] = enc.finish(tab);
-    a.err[c] = (peer & ENC_PUB_LOST) != 0u ? ERR_LIBRARY_CALL : (peer & ENC_PUB_BAD) != 0u ? ERR_INVALID_VALUE : enc.err;
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-    if (lane < 8)
-      a.out_bits[c] = stamp_sum[lane];
-    else if (lane < 16)
-      a.out_bits[c] = stamp_cnt[lane - 8];
-#endif
+    if (more)
+    {
+      enc.dump_when_room();
+      state[11 * a.C] = (uint32_t)enc.L;
+      state[12 * a.C] = enc.B;
+      state[13 * a.C] = enc.c1;
+      state[14 * a.C] = enc.tot;
+      state[15 * a.C] = enc.mps;
+    }
+    else
+      enc.finish(tab);
   }
+  peer_store(pub_mine, (rd & 0xFFFFu) | ((enc.rwr & 0xFFu) << 16) | ENC_PUB_DONE | (peer & ENC_PUB_BAD));
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
+  if (live && lane < 8) // (the writer of a diagnostic build leaves out_bits alone)
+    a.out_bits[c] = lane < 4 ? dg_n[lane] : dg_c[lane - 4];
+#endif
 }
 
-// PAIRS: 4 for batches of up to 64 Ki channels (one coding wave per SIMD is all there is); 8 -- with the smaller rings
-// <.., 4, 16, 24, ..> -- for larger ones: two coding waves per SIMD, and half as many workgroups to load the table.
-template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t ORING = ENC_ORING, bool W64 = false, bool F32IN = false,
-          uint32_t PAIRS = ENC_PAIRS>
-__global__ void __launch_bounds__(PAIRS * 128) dega_encode_kernel(const EncodeArgs a)
+// PAIRS: 4 groups of three waves (SPLIT: filler, coder, writer) for batches of up to 64 Ki channels -- one coding wave per
+// SIMD is all there is --; 8 pairs (coder + a helper that fills and writes), with the smaller rings <.., 4, 16, 8, 16, ..>,
+// for larger ones: two coding waves per SIMD, and half as many workgroups to load the table.
+template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t RAW = ENC_RAW, uint32_t ORING = ENC_ORING, bool W64 = false,
+          bool F32IN = false, uint32_t PAIRS = ENC_PAIRS, bool SPLIT = true>
+__global__ void __launch_bounds__(PAIRS * (SPLIT ? 192 : 128)) dega_encode_kernel(const EncodeArgs a)
 {
   constexpr uint32_t LDS_ROWS = (W64 && !F32IN) ? 2 * ROWS : ROWS;
-  static_assert(ORING >= ENC_WORD_MAX_OUT + 4, "rings too small");
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
-  // access with a vmcnt(0) wait):  division magics (64 KiB) | per pair: seg-bit ring, coded-word ring, input rows, the
-  // two published rows
+  // access with a vmcnt(0) wait):  division magics (64 KiB) | per group: seg-bit ring, raw ring, staging ring, input rows,
+  // the three published rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  constexpr uint32_t PER_PAIR = (RING + ORING + LDS_ROWS + 2) * 64;
+  constexpr uint32_t PER_PAIR = (RING + RAW + ORING + LDS_ROWS + 3) * 64;
   __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + PAIRS * PER_PAIR];
   static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
   uint32_t *const tab = lds;
@@ -583,29 +757,46 @@ __global__ void __launch_bounds__(PAIRS * 128) dega_encode_kernel(const EncodeAr
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = wave_uniform(threadIdx.x >> 6);
   const uint32_t pair = wave % PAIRS;
-  const bool codes = wave >= PAIRS;
+  // 0: fills (and writes, unless SPLIT), 1: codes, 2: writes.  Which wave of a group does what decides which is the oldest on
+  // its SIMD, and the oldest ready wave issues first when priorities tie (DG_ENC_ROLE_ORDER: measurement knob)
+#ifndef DG_ENC_ROLE_ORDER
+#define DG_ENC_ROLE_ORDER 0
+#endif
+  constexpr uint32_t role_of[4][3] = {{0, 1, 2}, {1, 2, 0}, {1, 0, 2}, {2, 1, 0}};
+  const uint32_t role = SPLIT ? role_of[DG_ENC_ROLE_ORDER][wave / PAIRS] : wave / PAIRS;
   uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
-  uint32_t *const ring_col = pair_lds + lane;                         // seg bits waiting to be coded
-  uint32_t *const oring_col = pair_lds + RING * 64 + lane;            // coded words waiting to be stored
-  uint32_t *const rows_wave = pair_lds + (RING + ORING) * 64;         // the next input rows (wave uniform)
-  uint32_t *const pub_filler = pair_lds + (RING + ORING + LDS_ROWS) * 64 + lane;
+  uint32_t *const ring_col = pair_lds + lane;                              // seg bits waiting to be coded
+  uint32_t *const raw_col = pair_lds + RING * 64 + lane;                   // the coder's dumps waiting to be absorbed
+  uint32_t *const oring_col = pair_lds + (RING + RAW) * 64 + lane;         // coded words waiting to be stored
+  uint32_t *const rows_wave = pair_lds + (RING + RAW + ORING) * 64;        // the next input rows (wave uniform)
+  uint32_t *const pub_filler = pair_lds + (RING + RAW + ORING + LDS_ROWS) * 64 + lane;
   uint32_t *const pub_coder = pub_filler + 64;
-  if (!codes) // nothing written, nothing consumed
+  uint32_t *const pub_writer = SPLIT ? pub_filler + 128 : pub_filler;
+  if (wave < PAIRS) // nothing written, nothing consumed, nothing absorbed
   {
     *pub_filler = 0;
     *pub_coder = 0;
+    pub_filler[128] = 0;
   }
-  load_div_table<ADAPTIVE>(tab, a.div_magic, (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
+  // (a launch that goes on from saved state may be anywhere in its channels' streams: the whole table)
+  load_div_table<ADAPTIVE>(tab, a.div_magic, a.seg_state != nullptr ? ~0ull : (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
 
   const size_t c_wave0 = (size_t)blockIdx.x * (PAIRS * 64u) + pair * 64u;
   const size_t c = c_wave0 + lane;
   const bool live = c < a.C;
   if (!wave_any(live))
-    return; // a pair past the last channel
-  if (codes)
-    encode_coding_wave<ADAPTIVE, RING, ORING>(a, tab, ring_col, oring_col, pub_coder, pub_filler, lane, c, live);
+    return; // a group past the last channel
+  if (role == 1)
+    encode_coding_wave<ADAPTIVE, RING, RAW, SPLIT>(a, tab, ring_col, raw_col, pub_coder, pub_filler, pub_writer, lane, c, live);
+  else if constexpr (SPLIT)
+  {
+    if (role == 0)
+      encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, true, false>(a, ring_col, raw_col, oring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
+    else
+      encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, false, true>(a, ring_col, raw_col, oring_col, rows_wave, pub_writer, pub_coder, lane, c, live, c_wave0);
+  }
   else
-    encode_filling_wave<NARROW, ROWS, RING, W64, F32IN>(a, ring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
+    encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, true, true>(a, ring_col, raw_col, oring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
 }
 
 // =====================================================================================================================

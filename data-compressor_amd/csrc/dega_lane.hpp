@@ -40,14 +40,18 @@ DG_DEV uint32_t div_shift(uint32_t t)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The encoder.
+// The encoder -- in two halves that run in two different waves of a pair (dega_kernels.hpp):
+//   BacCoder   the serial arithmetic: interval, model, renormalisation.  Nothing else: the coding wave's instruction
+//              stream is what bounds the kernel (one wave issues one instruction per 4.1 - 4.6 cycles whatever its
+//              partner does: profiles/r03_ubench2_issue_cost.txt), so everything that is not on the chain is gone from it.
+//   BacWriter  the output side: finished bits -> 32-bit words -> the channel's slab, in the partner wave.
+// Between them: a ring of RAW entries per lane, each the high dword of the coder's register L (below) at a dump.
 //
 // Interval state (bac.c:83-139) in a form whose renormalisation is branch free:
 //   A = start << 16,   B = (65535 - end) << 16   (low 16 bits always zero)
-// so that range - 1 = ~(A + B) >> 16, the E1/E2 shift count is clz(~(A ^ B)) (length of the common prefix of start and
-// end), and the number of E3 steps that follow is the run of ones below bit 31 of (A & B) after that shift.  After an
-// E3 step the reference clears the top bit of both; here it is left set in both ("spurious" bit 31): every use either
-// shifts it out or cancels it (A + B mod 2^32, A ^ B).
+// so that range - 1 = ~(A + B) >> 16 and the number of renormalisation shifts is one count-leading-zeros
+// (renorm_shifts).  After an E3 step the reference clears the top bit of both; here it is left set in both ("spurious"
+// bit 31): every use either shifts it out or cancels it (A + B mod 2^32, A ^ B).
 //
 // Output side: carry propagation instead of bit-plus-follow.  The reference emits a bit per E1/E2 shift and defers E3
 // shifts in a counter resolved by the next emitted bit (bac.c:93-105,127-132).  The stream it produces is exactly the
@@ -60,46 +64,57 @@ DG_DEV uint32_t div_shift(uint32_t t)
 // themselves).  The high dword starts as binary 10: the leading one is a sentinel whose position tells how many bits are
 // finished (no counter to keep per symbol), the zero below it takes a carry that runs past ALL finished bits (it can
 // take one: a pending run starts with a provisional 0, so a second such carry needs a new run, which stays inside).
-// Every few symbols the finished bits -- at most 30 fit -- are DUMPED into
-//   F    = finished bits not yet in whole words, right aligned, fcnt of them (< 32 between dumps, + the dump's <= 30,
+// Every few symbols the high dword -- at most 30 finished bits fit -- is DUMPED: written as it is into the lane's next
+// raw-ring slot and reset to binary 10.  That is all the coding wave does about output.
+//
+// The writer absorbs the entries in order:
+//   F    = finished bits not yet in whole words, right aligned, fcnt of them (< 32 between entries, + an entry's <= 30,
 //          + 1 for the carry: never more than 62, so F cannot overflow)
 //   prev = the last completed 32-bit word, held back from memory so that it can still absorb a carry out of F
-// and whole words are handed on: prev (+ that carry) to the lane's LDS column, the new word to prev.  A carry running even
-// past prev (33+ pending bits) ripples into the words already stored, which this lane wrote itself.
+// and hands whole words on: prev (+ that carry) to the lane's staging column, the new word to prev.  A carry running
+// even past prev (33+ pending bits) ripples into the words already stored, which this lane wrote itself.
 //
 // How many symbols may go between two dumps?  n symbols shift out fewer than 2 + sum(-log2 p_i) bits (the range starts
 // and ends the group in (Q, 4Q]), and no symbol is less probable than f2 / tot, so with tot <= 11 * f2 eight symbols
 // stay below 2 + 8 * 3.46 < 30 bits, and with tot <= 128 * f2 four do.  These are per-word preconditions (classify());
-// a lane outside both codes bit by bit and dumps after every symbol.
+// a lane outside both codes bit by bit and dumps whenever 15 or more bits are finished (a symbol adds at most 16).
 //
 // Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
 // frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t ENC_WORD_MAX_OUT = 8; // the most one 32-symbol word path can complete: 8 groups of < 30 bits
-constexpr uint32_t ENC_ORING = 32;       // staged output words per lane; word paths need ENC_WORD_MAX_OUT free slots
+constexpr uint32_t ENC_RAW = 16;   // raw-ring entries per lane (narrow batches); a word path needs up to 8 free
+constexpr uint32_t ENC_ORING = 32; // staged output words per lane on the writer's side (drained in groups of 16)
 
 // classes of the next 32 symbols of a lane, cheapest first (the wave takes the most expensive one any of its lanes needs)
 constexpr uint32_t CLS_FAST8 = 0;   // no model event possible, a dump every 8 symbols is enough
 constexpr uint32_t CLS_SPLIT = 1;   // as FAST8 but for ONE halving of the counts inside the word: coded in two parts (see below)
 constexpr uint32_t CLS_FAST4 = 2;   // no model event possible, skewed counts: a dump every 4 symbols
 constexpr uint32_t CLS_GENERAL = 3; // halving / MPS-LPS swap / division-shift change handled by selects, dump every 4
-constexpr uint32_t CLS_BITS = 4;    // bit at a time: first word of a channel, extreme counts
+constexpr uint32_t CLS_BITS = 4;    // bit at a time: extreme counts
 
-template <bool ADAPTIVE, uint32_t ORING = ENC_ORING>
-struct BacEncoder
+// The number of renormalisation shifts (E1/E2 + E3, bac.c:112-137) of the interval (a, b) in the representation above.
+// U = ~(a ^ b) is zero over the common prefix of start and end (k bits: the E1/E2 shifts), one at the first difference --
+// start 0, end 1 -- and one over the E3 run below it (start 1, end 0, i.e. a = b = 1), which is exactly where V = a & b has
+// its leading run, one bit lower.  So U ^ (V << 1) is zero over prefix and run and one right after: its leading zeros
+// are k + e.  (Whatever V holds further down only reaches bits below that one; the low 16 bits of U are ones, so the
+// count is at most 16; spurious top bits: U's bit 31 is one then, k = 0, and V's bit 31 is shifted out.)
+DG_DEV uint32_t renorm_shifts(uint32_t a, uint32_t b)
 {
+  const uint32_t v = a & b;
+  return clz32(~(a ^ b) ^ (v + v));
+}
+
+template <bool ADAPTIVE, uint32_t RAW = ENC_RAW>
+struct BacCoder
+{
+  static_assert((RAW & (RAW - 1)) == 0 && RAW >= 8 && RAW <= 128, "raw ring: a power of two, room for a word path's 8 entries, counted modulo 256");
   uint64_t L; // low dword: A; high dword: sentinel, carry slot, finished bits (see above)
   uint32_t B;
   uint32_t c1, tot, mps;
-  uint64_t F;
-  uint32_t fcnt;
-  uint32_t prev, pos;       // pos = words completed so far; prev is word pos-1 (held back)
-  uint32_t drained, staged; // words [0, drained) are in the slab, [drained, drained + staged) in the lane's LDS column
-  uint32_t cap_words;
-  uint32_t *dst;   // channel's slab (global memory)
-  uint32_t *oring; // lane's column of the LDS output ring: slot s at oring[s * 64]
-  int32_t err;
-  uint32_t safe;   // words that may still be coded in class `cls` before the preconditions have to be looked at again
+  uint32_t *raw;        // lane's column of the raw ring: entry e at raw[(e % RAW) * 64]
+  uint32_t rwr;         // entries written so far
+  const uint32_t *peer; // the writer's published word of this lane (entries absorbed, modulo 256, in bits 16..23)
+  uint32_t safe;        // words that may still be coded in class `cls` before the preconditions have to be looked at again
   uint32_t cls;
   // The symbols of the next word that the next word path codes: all 32 -- or, around a halving of the counts (CLS_SPLIT),
   // first 0 .. h (h = the symbol whose update halves, bac.c:57), then, a step later, h+1 .. 31.  The other symbols of
@@ -110,23 +125,16 @@ struct BacEncoder
   uint32_t part_lo, part_hi;
   bool part_halves; // the two parts meet at a halving of the counts (else: at a change of the division shift)
 
-  DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
+  DG_DEV void init(uint32_t *raw_, const uint32_t *peer_)
   {
     L = (uint64_t)2 << 32; // bac.c:86-91: start = 0; no finished bits
     B = 0;
     c1 = 2; // bac.c:39-52
     tot = 3;
     mps = 0;
-    F = 0;
-    fcnt = 0;
-    prev = 0;
-    pos = 0;
-    drained = 0;
-    staged = 0;
-    cap_words = cap_words_;
-    dst = dst_;
-    oring = oring_;
-    err = OK;
+    raw = raw_;
+    rwr = 0;
+    peer = peer_;
     safe = 0;
     cls = CLS_BITS;
     part_lo = 0;
@@ -139,150 +147,39 @@ struct BacEncoder
     return (uint32_t)L;
   }
 
-  // ---- memory side ---------------------------------------------------------------------------------------------------
+  // ---- the raw ring ------------------------------------------------------------------------------------------------------
 
-  DG_DEV void put_word(uint32_t index, uint32_t word)
+  DG_DEV static bool raw_room(uint32_t written, uint32_t peer_word, uint32_t entries) // room for `entries` more
   {
-    if (index < cap_words)
-      dst[index] = bswap32(word); // MSB-first bit order => big-endian words
-    else if (err == OK)
-      err = ERR_MEMORY;
+    return ((written - (peer_word >> 16)) & 0xFFu) + entries <= RAW;
   }
 
-  DG_DEV void drain_lane() // LDS column -> slab, this lane only (the kernel normally drains whole waves in lockstep)
+  DG_DEV void dump() // the caller has made sure of room
   {
-    for (uint32_t s = 0; s < staged; s++)
-      put_word(drained + s, oring[s * 64u]);
-    drained += staged;
-    staged = 0;
-  }
-
-  // Four staged words (slots s .. s+3) as one 16-byte store: scattered stores cost per instruction, not per byte.
-  DG_DEV void put_group(uint32_t index, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
-  {
-    if (index + 4u <= cap_words)
-    {
-      store_x4(dst + index, bswap32(w0), bswap32(w1), bswap32(w2), bswap32(w3));
-    }
-    else
-    {
-      put_word(index, w0);
-      put_word(index + 1u, w1);
-      put_word(index + 2u, w2);
-      put_word(index + 3u, w3);
-    }
-  }
-
-  DG_DEV void push_word(uint32_t word)
-  {
-    if (staged == ORING)
-      drain_lane();
-    oring[staged * 64u] = word;
-    staged++;
-  }
-
-  // add one to the big number formed by words [0, count): the staged ones first, then the slab (rare: a carry past `prev`)
-  DG_DEV void ripple_carry_from(uint32_t count)
-  {
-    drain_lane();
-    while (count > 0)
-    {
-      --count;
-      if (count < cap_words)
-      {
-        const uint32_t w = bswap32(dst[count]) + 1u;
-        dst[count] = bswap32(w);
-        if (w != 0)
-          break;
-      }
-    }
-  }
-
-  // ---- finished bits -> words ------------------------------------------------------------------------------------------
-
-  // L's finished bits (and the carry above them) move to F.  Exact for any state with at most 30 finished bits.
-  DG_DEV void dump()
-  {
-    const uint32_t hi = (uint32_t)(L >> 32);
-    const uint32_t fb = 30u - clz32(hi);          // the sentinel sits at bit fb + 1
-    const uint32_t v = hi - (2u << fb);           // finished bits, the carry (if any) at bit fb
+    raw[(rwr % RAW) * 64u] = (uint32_t)(L >> 32);
     L = ((uint64_t)2 << 32) | (uint32_t)L;
-    F = (F << fb) + v;                            // the carry adds into the bits F already holds
-    fcnt += fb;
+    rwr++;
   }
 
-  // One whole word out of F if it holds one (fcnt >= 32): prev, plus the carry that came up through F, goes to the LDS
-  // column; the new word is held back.  The general form, for the bit path and the end of the stream.
-  DG_DEV void hand_off()
+  // The slow paths (bit at a time, end of stream) make sure themselves: the writer is another wave and never waits for
+  // this one, so the wait ends.  (Only lanes of such a path are active here; the others wait at the reconvergence.)
+  DG_DEV void dump_when_room()
   {
-    if (fcnt < 32u)
-      return;
-    const uint32_t sh = fcnt - 32u;
-    const uint64_t top = F >> sh; // the word, above it the carry (0 or 1)
-    const uint32_t carry = (uint32_t)(top >> 32);
-    if (pos > 0u)
-    {
-      const uint32_t sum = prev + carry;
-      if (sum < carry) // prev was all ones: the carry runs on into words already handed on
-        ripple_carry_from(pos - 1u);
-      push_word(sum);
-    }
-    pos++;
-    prev = (uint32_t)top;
-    F = (uint32_t)F & ((1u << sh) - 1u);
-    fcnt = sh;
+    while (!raw_room(rwr, peer_load(peer), 1u))
+      wave_sleep<1>();
+    dump();
   }
 
-  // The same inside a word path: branch free, pos >= 1, room in the LDS column guaranteed by the caller.  A carry running
-  // past prev (prev all ones: once in 2^32 hand-overs of random data) is only RECORDED -- bit g of `ovf` for the g-th
-  // hand-over of the word, with `took` telling which hand-overs completed a word -- and settled after the word
-  // (settle_ripples): the words it has to run into are all in the column or the slab by then, and adding one to a
-  // multi-word number can be done at any time.
-  DG_DEV void hand_off_in_word(uint32_t &took, uint32_t &ovf)
+  // a bit-at-a-time word is over: flush, and leave the entry count a multiple of 4 (the fast word path's four entries then
+  // never wrap inside the ring: one address, four offsets); an entry of binary 10 holds no bits
+  DG_DEV void end_bits_word()
   {
-    const uint32_t m = (uint32_t)((int32_t)(31u - fcnt) >> 31); // all ones when a word is complete
-    const uint32_t sh = (fcnt - 32u) & 31u;
-    const uint64_t top = F >> sh;                               // the word, above it the carry; garbage when m == 0
-    const uint32_t carry = (uint32_t)(top >> 32) & m;
-    const uint32_t sum = prev + carry;
-    ovf = (ovf << 1) | (sum < carry ? 1u : 0u);
-    took = (took << 1) | (m & 1u);
-    oring[staged * 64u] = sum; // harmless when no word is complete: the slot is rewritten by the next one
-    staged += m & 1u;
-    pos += m & 1u;
-    prev = select32(m, (uint32_t)top, prev);
-    const uint32_t keep = (uint32_t)F & ((1u << sh) - 1u);
-    F = m ? (uint64_t)keep : F;
-    fcnt = select32(m, sh, fcnt);
-  }
-
-  DG_DEV void settle_word(uint32_t record, uint32_t groups) // record: what encode_word returned (non-zero)
-  {
-    settle_ripples(record & 0xFFu, (record >> 16) & 0xFFu, groups);
-  }
-
-  // After a word path with `groups` hand-overs: the recorded carries past prev, each into the words in front of the word
-  // that was held back at the time.
-  DG_DEV void settle_ripples(uint32_t took, uint32_t ovf, uint32_t groups)
-  {
-    uint32_t p = pos; // words completed now; walk the hand-overs backwards
-    for (uint32_t g = 0; g < groups; g++)
-    {
-      const uint32_t t = (took >> g) & 1u;
-      p -= t; // completed words before this hand-over
-      if ((ovf >> g) & 1u)
-        ripple_carry_from(p - 1u); // the held-back word was word p - 1; the carry goes into the words in front of it
-    }
+    do
+      dump_when_room();
+    while ((rwr & 3u) != 0u);
   }
 
   // ---- one symbol, every special case handled in place -----------------------------------------------------------------
-
-  DG_DEV uint32_t renormalise_count(uint32_t a, uint32_t b) const // bac.c:112-137: the number of shifts (E1/E2 + E3)
-  {
-    const uint32_t k = clz32(~(a ^ b)); // <= 16: the low halves differ by construction
-    const uint32_t v = ((a & b) << k) | 0x80000000u;
-    return k + clz32(~v) - 1u; // run of ones below bit 31; ~v != 0 because the low 16 bits of v are zero
-  }
 
   DG_DEV void update_model(bool lps) // bac.c:54-81
   {
@@ -318,47 +215,32 @@ struct BacEncoder
       inc = mulhi32(R, M) >> sh; // ... start += range * cum[2] / cum[0], cum[2] = 1   (bac.c:110-111)
     }
     L += (uint64_t)(inc << 16);
-    const uint32_t n = renormalise_count(A(), B); // <= 16
+    const uint32_t n = renorm_shifts(A(), B); // <= 16
     L <<= n;
     B <<= n;
-    dump();
-    hand_off();
+    if ((uint32_t)(L >> 32) >= 0x10000u) // 15 or more bits finished: the next symbol's 16 might not fit
+      dump_when_room();
     if (ADAPTIVE)
       update_model(lps);
     safe = 0; // the model moved outside a word path: classify again
   }
 
-  // EOF symbol + FinishEncoding (bac.c:163-164, 141-145); returns the exact stream length in bits
-  DG_DEV uint64_t finish(const uint32_t *magic)
+  // EOF symbol + FinishEncoding (bac.c:163-164, 141-145): the last entries of the lane
+  DG_DEV void finish(const uint32_t *magic)
   {
     const uint32_t a = A();
     const uint32_t R = ((~(a + B)) >> 16) + 1u;
     const uint32_t x2 = mulhi32(R, magic[tot]) >> div_shift(tot); // index 3: cum[2] = 1, cum[3] = 0
     B = 0u - (a + (x2 << 16));                                     // end = start + x2 - 1, start unchanged
-    const uint32_t n = renormalise_count(a, B);
+    const uint32_t n = renorm_shifts(a, B);
     L <<= n;
     B <<= n;
-    dump();
-    hand_off();
+    dump_when_room();
     // "pending++ ; emit (start < Q ? 0 : 1) and the pending inverse bits" == round the window up to the next multiple
     // of Q and emit its top two bits (the carry resolves any pending run).
     L += (uint64_t)0x40000000u;
     L <<= 2;
-    dump();
-    hand_off();
-    // what is left: prev, then the fcnt < 32 bits of F, zero padded (bit_file_buffer.c:310-320)
-    const uint32_t carry = (uint32_t)(F >> fcnt) & 1u;
-    if (pos > 0)
-    {
-      const uint32_t sum = prev + carry;
-      if (sum < carry)
-        ripple_carry_from(pos - 1u);
-      push_word(sum);
-    }
-    drain_lane();
-    if (fcnt > 0)
-      put_word(pos, (uint32_t)F << (32u - fcnt));
-    return (uint64_t)pos * 32u + fcnt;
+    dump_when_room();
   }
 
   // ---- the class of the next word, and for how many words it holds -------------------------------------------------------
@@ -370,12 +252,6 @@ struct BacEncoder
   //   dump capacity       tot <= 11 * f2 (eight symbols) or tot <= 128 * f2 (four), up to the end of each word
   DG_DEV void classify()
   {
-    if (pos == 0u) // nothing is held back yet: the hand-off of the first word is special
-    {
-      cls = CLS_BITS;
-      safe = 0;
-      return;
-    }
     if (!ADAPTIVE)
     {
       cls = CLS_FAST8; // counts 1 : 1 : 1 forever: 8 symbols shift out fewer than 2 + 8 * log2(3) < 15 bits
@@ -465,27 +341,18 @@ struct BacEncoder
     return true;
   }
 
-  // The 32 division magics of the word that a lane would code next with a fast word path (cum[0] = tot .. tot+31).
-  // The kernel fetches them from LDS right after a code step, so that the (bank-conflicting, per-lane scattered) reads
-  // and their latency overlap the fill and drain phases instead of heading the next word.
-  // the first quarter (see encode_word); all a static model ever needs
+  // The first quarter of the division magics of the word that a lane would code next with a fast word path
+  // (cum[0] = tot .. tot+7; all a static model ever needs).  The kernel fetches them at the top of its step, together
+  // with the queued word; the other quarters follow inside the word path (see encode_word).
   DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const
   {
     const uint32_t *const mg = magic + (tot - part_lo); // symbol i is coded with cum[0] = tot + (i - part_lo)
 #pragma unroll
     for (uint32_t i = 0; i < (ADAPTIVE ? 8u : 1u); i++)
-      Mg[i] = mg[i];
-  }
-
-  DG_DEV void fetch_magics(const uint32_t *magic, uint32_t (&Mg)[32]) const
-  {
-    const uint32_t *const mg = magic + (tot - part_lo);
-#pragma unroll
-    for (uint32_t i = 0; i < (ADAPTIVE ? 32u : 1u); i++)
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
       Mg[i] = 0x40000000u + tot * 131u + i; // diagnostic build: no table reads
 #else
-      Mg[i] = mg[i]; // past the table's end for tot > 16352: never used then (no fast class)
+      Mg[i] = mg[i];
 #endif
   }
 
@@ -493,16 +360,13 @@ struct BacEncoder
   // GENERAL = false: no model event can occur in the word (classes FAST8 / FAST4): the magics come in registers, the
   //                  counts change only by c1 -= lps.
   // GENERAL = true : the whole model update of bac.c:54-81 by selects; magics read from the table as the counts move.
-  // DUMP: symbols between two dumps (8 or 4).
-  // Returns 0, or -- when a carry ran past the held-back word -- the record for settle_word().
+  // DUMP: symbols between two dumps (8 or 4): 32 / DUMP raw entries, for which the caller has made sure of room.
   // MASKED: only the symbols part_lo .. part_hi are coded, the others are no-ops (CLS_SPLIT; fast path only).
   template <bool GENERAL, uint32_t DUMP, bool MASKED = false>
-  DG_DEV uint32_t encode_word(uint32_t word, const uint32_t *magic, uint32_t (&Mg)[32])
+  DG_DEV void encode_word(uint32_t word, const uint32_t *magic, uint32_t (&Mg)[32])
   {
     static_assert(!GENERAL || ADAPTIVE, "the static model never needs the general path");
     static_assert(!MASKED || (!GENERAL && ADAPTIVE), "parts of words are a matter of the adaptive fast path");
-    static_assert(32 / DUMP <= 8, "the record of a word's hand-overs has 8 + 8 bits");
-    uint32_t took = 0, ovf = 0;
     uint32_t mm = 0u - mps;                          // all ones when the MPS is the bit value 1
     // symbol i <-> bit 31 - i; a symbol that is not coded becomes a more probable one with magic 0
     const uint32_t active = MASKED ? (0xFFFFFFFFu >> part_lo) & (0xFFFFFFFFu << (31u - part_hi)) : 0xFFFFFFFFu;
@@ -510,6 +374,8 @@ struct BacEncoder
     const uint32_t sh_word = div_shift(tot);
     const uint32_t tot_word = tot - (MASKED ? part_lo : 0u);
     uint32_t Mcur = GENERAL ? magic[tot] : 0u;
+    // the word's raw entries: with four of them (and the entry count a multiple of 4: end_bits_word) one address will do
+    uint32_t *const slot = raw + (rwr % RAW) * 64u;
     // The 32 division magics of a fast word are scattered, bank-conflicting LDS reads: all at once they take a few hundred
     // cycles to land, and whoever needs an LDS answer meanwhile waits for the lot (LDS answers in order; the compiler
     // waits for "all outstanding").  So they come in quarters: Mg[0..7] are fetched by the caller a little ahead of the
@@ -552,11 +418,9 @@ struct BacEncoder
       const uint32_t x2 = mulhi32(R, M) >> sh;                // range * cum[2] / cum[0], cum[2] = 1
       const uint32_t inc = select32(lm, x2, x1);
       B = select32(lm, 0u - (a + (x1 << 16)), B);
-      L += (uint64_t)(inc << 16); // the carry out of A lands in the finished bits
+      L = add_shifted16(L, inc); // the carry out of A lands in the finished bits
       // renormalise: A and the finished bits move together
-      const uint32_t a2 = (uint32_t)L;
-      const uint32_t k = clz32(~(a2 ^ B));
-      const uint32_t n = k + leading_ones(((a2 & B) << k) | 0x80000000u) - 1u;
+      const uint32_t n = renorm_shifts((uint32_t)L, B);
       L <<= n;
       B <<= n;
       if (GENERAL)
@@ -572,8 +436,12 @@ struct BacEncoder
         c1 -= lm; // f2++ for an LPS; tot is implicit (Mg[i])
       if ((i % DUMP) == DUMP - 1)
       {
-        dump();
-        hand_off_in_word(took, ovf);
+        // dump: the finished bits leave as they are
+        if (DUMP == 8)
+          slot[(i / DUMP) * 64u] = (uint32_t)(L >> 32);
+        else
+          raw[((rwr + i / DUMP) % RAW) * 64u] = (uint32_t)(L >> 32);
+        L = ((uint64_t)2 << 32) | (uint32_t)L;
       }
       if (!GENERAL && ADAPTIVE && (i == 0u || i == 8u || i == 16u))
       {
@@ -581,15 +449,202 @@ struct BacEncoder
         const uint32_t *const mq = magic + tot_word + i + 8u;
 #pragma unroll
         for (uint32_t k = 0; k < 8u; k++)
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 4)
+          Mg[i + 8u + k] = 0x40000000u + tot_word * 131u + i + k;
+#else
           Mg[i + 8u + k] = mq[k];
+#endif
         DG_COMPILER_BARRIER();
       }
     }
+    rwr += NSYM / DUMP;
     if (GENERAL)
       mps = mm & 1u;
     else if (ADAPTIVE)
       tot += MASKED ? part_hi - part_lo + 1u : 32u;
-    return ovf != 0u ? took | 0x80000000u | (ovf << 16) : 0u; // nearly always 0: see settle_ripples()
+  }
+};
+
+// The output side of a lane: raw entries in, 32-bit words out (see above).  Runs in the coder's partner wave.
+template <uint32_t ORING = ENC_ORING>
+struct BacWriter
+{
+  uint64_t F;
+  uint32_t fcnt;
+  uint32_t prev, pos;       // pos = words completed so far; prev is word pos-1 (held back)
+  uint32_t drained, staged; // words [0, drained) are in the slab, [drained, drained + staged) in the lane's LDS column
+  uint32_t cap_words;
+  uint32_t *dst;   // channel's slab (global memory)
+  uint32_t *oring; // lane's column of the LDS staging ring: word w at oring[(w % ORING) * 64]
+  int32_t err;
+
+  DG_DEV void init(uint32_t *dst_, uint32_t cap_words_, uint32_t *oring_)
+  {
+    F = 0;
+    fcnt = 0;
+    prev = 0;
+    pos = 0;
+    drained = 0;
+    staged = 0;
+    cap_words = cap_words_;
+    dst = dst_;
+    oring = oring_;
+    err = OK;
+  }
+
+  DG_DEV void put_word(uint32_t index, uint32_t word)
+  {
+    if (index < cap_words)
+      dst[index] = bswap32(word); // MSB-first bit order => big-endian words
+    else if (err == OK)
+      err = ERR_MEMORY;
+  }
+
+  DG_DEV void drain_lane() // LDS column -> slab, this lane only (the kernel normally drains whole waves in lockstep)
+  {
+    for (uint32_t s = 0; s < staged; s++)
+      put_word(drained + s, oring[((drained + s) % ORING) * 64u]);
+    drained += staged;
+    staged = 0;
+  }
+
+  // Four staged words as one 16-byte store: scattered stores cost per instruction, not per byte.
+  DG_DEV void put_group(uint32_t index, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+  {
+    if (index + 4u <= cap_words)
+    {
+      store_x4(dst + index, bswap32(w0), bswap32(w1), bswap32(w2), bswap32(w3));
+    }
+    else
+    {
+      put_word(index, w0);
+      put_word(index + 1u, w1);
+      put_word(index + 2u, w2);
+      put_word(index + 3u, w3);
+    }
+  }
+
+  DG_DEV void push_word(uint32_t word)
+  {
+    if (staged == ORING)
+      drain_lane();
+    oring[((drained + staged) % ORING) * 64u] = word;
+    staged++;
+  }
+
+  // add one to the big number formed by words [0, count): the staged ones first, then the slab (rare: a carry past `prev`)
+  DG_DEV void ripple_carry_from(uint32_t count)
+  {
+    drain_lane();
+    while (count > 0)
+    {
+      --count;
+      if (count < cap_words)
+      {
+        const uint32_t w = bswap32(dst[count]) + 1u;
+        dst[count] = bswap32(w);
+        if (w != 0)
+          break;
+      }
+    }
+  }
+
+  // One whole word out of F if it holds one (fcnt >= 32): prev, plus the carry that came up through F, goes to the
+  // staging column; the new word is held back.
+  DG_DEV void hand_off()
+  {
+    if (fcnt < 32u)
+      return;
+    const uint32_t sh = fcnt - 32u;
+    const uint64_t top = F >> sh; // the word, above it the carry (0 or 1)
+    const uint32_t carry = (uint32_t)(top >> 32);
+    if (pos > 0u)
+    {
+      const uint32_t sum = prev + carry;
+      if (sum < carry) // prev was all ones: the carry runs on into words already handed on
+        ripple_carry_from(pos - 1u);
+      push_word(sum);
+    }
+    pos++;
+    prev = (uint32_t)top;
+    F = (uint32_t)F & ((1u << sh) - 1u);
+    fcnt = sh;
+  }
+
+  // One raw entry of the coder: its finished bits (and the carry above them) join F.  Exact for any entry with at
+  // most 30 finished bits; an entry of binary 10 changes nothing.
+  DG_DEV void absorb(uint32_t hi)
+  {
+    const uint32_t fb = 30u - clz32(hi);          // the sentinel sits at bit fb + 1
+    const uint32_t v = hi - (2u << fb);           // finished bits, the carry (if any) at bit fb
+    F = (F << fb) + v;                            // the carry adds into the bits F already holds
+    fcnt += fb;
+    hand_off();
+  }
+
+  // The four entries of a fast word step at once, when F can take them all -- fewer than 64 bits with what it holds, so at
+  // most one word completes: the usual case by far (a word step finishes 28 bits on this data, a word at most)
+  DG_DEV bool fits4(const uint32_t (&hi)[4]) const
+  {
+    return fcnt + (120u - clz32(hi[0]) - clz32(hi[1]) - clz32(hi[2]) - clz32(hi[3])) < 64u;
+  }
+
+  DG_DEV void absorb4(const uint32_t (&hi)[4])
+  {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+    {
+      const uint32_t fb = 30u - clz32(hi[k]);
+      F = (F << fb) + (hi[k] - (2u << fb));
+      fcnt += fb;
+    }
+    hand_off();
+  }
+
+  // The same for a whole wave in step, branch free: fits4(), a word held back already (pos >= 1) and room in the staging
+  // column are the caller's business.  Returns true when a carry ran past the held-back word (it was all ones: once in
+  // 2^32 hand-overs of random data): the caller then calls ripple_carry_from(pos - 2) -- the word just staged is word
+  // pos - 2, the carry belongs in the words in front of it.
+  DG_DEV bool absorb4_in_step(const uint32_t (&hi)[4])
+  {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+    {
+      const uint32_t fb = 30u - clz32(hi[k]);
+      F = (F << fb) + (hi[k] ^ (2u << fb)); // (the sentinel bit is set: xor takes it out)
+      fcnt += fb;
+    }
+    const uint32_t m = (uint32_t)((int32_t)(31u - fcnt) >> 31); // all ones when a word is complete
+    const uint32_t sh = (fcnt - 32u) & 31u;
+    const uint64_t top = F >> sh;                               // the word, above it the carry; garbage when m == 0
+    const uint32_t carry = (uint32_t)(top >> 32) & m;
+    const uint32_t sum = prev + carry;
+    oring[((drained + staged) % ORING) * 64u] = sum; // harmless when no word is complete: the slot is rewritten by the next one
+    staged += m & 1u;
+    pos += m & 1u;
+    prev = select32(m, (uint32_t)top, prev);
+    const uint32_t keep = (uint32_t)F & ((1u << sh) - 1u);
+    F = m ? (uint64_t)keep : F;
+    fcnt = select32(m, sh, fcnt);
+    return sum < carry;
+  }
+
+  // What is left when the coder is through: prev, then the fcnt < 32 bits of F, zero padded (bit_file_buffer.c:310-320).
+  // Returns the exact stream length in bits.
+  DG_DEV uint64_t finish()
+  {
+    const uint32_t carry = (uint32_t)(F >> fcnt) & 1u;
+    if (pos > 0)
+    {
+      const uint32_t sum = prev + carry;
+      if (sum < carry)
+        ripple_carry_from(pos - 1u);
+      push_word(sum);
+    }
+    drain_lane();
+    if (fcnt > 0)
+      put_word(pos, (uint32_t)F << (32u - fcnt));
+    return (uint64_t)pos * 32u + fcnt;
   }
 };
 
@@ -721,11 +776,10 @@ struct BitQueue
   {
     const uint32_t n = 63u - 2u * clz32(w);
     acc = (acc << n) | w;
-    cnt += n;
-    const uint32_t full = cnt >= 32u ? 1u : 0u;
+    cnt += n; // < 64
     ring_col[(wr % RING) * 64u] = (uint32_t)(acc >> ((cnt - 32u) & 63u));
-    wr += full;
-    cnt -= full << 5;
+    wr += cnt >> 5; // a word is complete when cnt >= 32 ...
+    cnt &= 31u;     // ... and leaves cnt - 32 bits behind
   }
 
   template <uint32_t RING>
@@ -835,7 +889,7 @@ struct BacDecoder
   uint32_t A, B, D;
   uint32_t c1, tot, mps;
   uint64_t bp; // stream bits consumed so far
-  // The symbols of the next word that the next masked word path decodes (as BacEncoder::part_lo / part_hi): all 32, or --
+  // The symbols of the next word that the next masked word path decodes (as BacCoder::part_lo / part_hi): all 32, or --
   // around a halving of the counts -- first 0 .. h, then, a step later, h+1 .. 31; part_bits keeps the first part's bits.
   uint32_t part_lo, part_hi, part_bits;
   bool part_halves; // the first part ends at a halving of the counts (else: at a change of the division shift, or nowhere)
@@ -864,15 +918,13 @@ struct BacDecoder
 
   DG_DEV uint32_t renormalise()
   {
-    const uint32_t k = clz32(~(A ^ B));
-    const uint32_t v = ((A & B) << k) | 0x80000000u;
-    const uint32_t n = k + clz32(~v) - 1u;
+    const uint32_t n = renorm_shifts(A, B);
     A <<= n;
     B <<= n;
     return n;
   }
 
-  DG_DEV void update_model(bool lps) // as BacEncoder::update_model (bac.c:54-81)
+  DG_DEV void update_model(bool lps) // as BacCoder::update_model (bac.c:54-81)
   {
     if (tot == MAX_FREQUENCY)
     {
@@ -949,7 +1001,7 @@ struct BacDecoder
   }
 
   // The next word holds a halving of the counts (bac.c:57) and nothing else the fast path cannot do -- or its first part
-  // has been decoded already: the masked word path takes it, in two steps (see BacEncoder::classify, CLS_SPLIT: the
+  // has been decoded already: the masked word path takes it, in two steps (see BacCoder::classify, CLS_SPLIT: the
   // counts are in the top half of their range, and f1 - f2 >= 96 rules a swap out on both sides of the halving).
   DG_DEV bool halving_ahead() const // the only event of the next word is a halving, with room to spare (see above)
   {
@@ -986,7 +1038,7 @@ struct BacDecoder
   // After a masked word path that came through; `bits` = its symbols (the others zero).  Returns true when the word is
   // complete (then `bits` is the whole word).  After the first part of a halving word the update of symbol part_hi, which
   // the word path applied as a plain count, is redone as UpdateModel does it: halve, count the symbol, cum[0]++
-  // (BacEncoder::after_part); at a change of the division shift the counts just go on.
+  // (BacCoder::after_part); at a change of the division shift the counts just go on.
   DG_DEV bool after_part(uint32_t &bits)
   {
     bits |= part_bits;
@@ -1015,9 +1067,9 @@ struct BacDecoder
   // checkpoint and goes bit by bit -- if an EOF symbol turned up, or if one group of 4 symbols consumed more than 32
   // stream bits (the 32-bit look-ahead is rebuilt every 4 symbols), or if the word needed more than the 4 staged words.
   // GENERAL = false: no model event (halving, MPS/LPS swap, division-shift change) can occur in the word (fast_ok()).
-  // GENERAL = true : the whole model update of bac.c:54-81 by selects, as in BacEncoder::encode_word_general.
-  // as BacEncoder::fetch_magics: the kernel issues these reads a phase early
-  DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const // as BacEncoder::fetch_magics_first
+  // GENERAL = true : the whole model update of bac.c:54-81 by selects, as in BacCoder::encode_word_general.
+  // as BacCoder::fetch_magics: the kernel issues these reads a phase early
+  DG_DEV void fetch_magics_first(const uint32_t *magic, uint32_t (&Mg)[32]) const // as BacCoder::fetch_magics_first
   {
     const uint32_t *const mg = magic + (tot - part_lo);
 #pragma unroll
@@ -1085,15 +1137,14 @@ struct BacDecoder
       }
       else if (ADAPTIVE)
         c1 -= lm;
-      const uint32_t k = clz32(~(A ^ B));
-      const uint32_t n = k + leading_ones(((A & B) << k) | 0x80000000u) - 1u;
+      const uint32_t n = renorm_shifts(A, B);
       A <<= n;
       B <<= n;
       const uint64_t da = (((uint64_t)D << 32) | ahead) << n; // D takes the next n bits
       D = (uint32_t)(da >> 32);
       ahead = (uint32_t)da;
       off += n;
-      if (!GENERAL && ADAPTIVE && (i == 0u || i == 8u || i == 16u)) // the next quarter of the magics (see BacEncoder::encode_word)
+      if (!GENERAL && ADAPTIVE && (i == 0u || i == 8u || i == 16u)) // the next quarter of the magics (see BacCoder::encode_word)
       {
         DG_COMPILER_BARRIER();
         const uint32_t *const mq = magic + tot_word + i + 8u;

@@ -380,10 +380,13 @@ struct Slot
   GrowDev a, b, meta; // encode: a = samples, then the packed streams; b = slabs.  decode: a = packed streams, b = slabs, c = samples
   GrowDev c;
   GrowPin hmeta, stage;
-  // uploads / downloads in bands of rows beside the running kernel (few, long channels): the copies' stream, the progress
-  // word of the encode kernel and the values it takes (decode: the waves' progress words, written by the kernel)
+  // few, long channels: encode uploads the rows in bands and codes every band as it lands (one launch per band, the lanes'
+  // state saved in between: EncodeArgs::seg_state); decode downloads in bands beside the running kernel.  The copies'
+  // stream, one event per band, the state of the encode launches / the waves' progress words of the decode kernel.
   hipStream_t s2 = nullptr;
-  GrowDev progress;
+  std::vector<hipEvent_t> band_ev;
+  hipEvent_t reuse_ev = nullptr;
+  GrowDev seg_state;
   GrowPin progress_values;
 };
 
@@ -392,7 +395,6 @@ constexpr int MAX_SLOTS = 16;
 struct Pipeline
 {
   Slot slot[MAX_SLOTS];
-  bool bands_broken = false; // an encode kernel once gave up waiting for its rows: no more uploads beside running kernels
   GrowDev redo_slabs, redo_packed, redo_meta;
   GrowPin redo_hmeta;
   Stager stager;
@@ -446,7 +448,12 @@ static void pipeline_destroy(Pipeline *p)
       (void)hipStreamDestroy(sl.s);
     if (sl.s2 != nullptr)
       (void)hipStreamDestroy(sl.s2);
-    sl.progress.release();
+    for (hipEvent_t e : sl.band_ev)
+      (void)hipEventDestroy(e);
+    sl.band_ev.clear();
+    if (sl.reuse_ev != nullptr)
+      (void)hipEventDestroy(sl.reuse_ev);
+    sl.seg_state.release();
     sl.progress_values.release();
     sl.a.release();
     sl.b.release();
@@ -533,10 +540,11 @@ static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes
   return p;
 }
 
-// Rows per upload band when the samples of a chunk go up beside its running kernel (0: upload first, the usual way).
-// Only worth it when there are too few chunks to overlap one chunk's copy with another's kernel and the channels are long;
-// bands end on multiples of 32 rows, so that no 128-byte line of the device array holds rows of two bands (a line read
-// with the last rows of one band must not carry stale bytes of the next), and are about 32 MiB each.
+// Rows per band when a chunk's samples cross the link in bands (0: in one piece, the usual way): encode codes every band
+// with a launch of its own as soon as it has landed -- plain stream order, an event per band; nothing on the device ever
+// waits for the host -- and decode sends every band home as soon as all waves have stored it.  Only worth it when there
+// are too few chunks to overlap one chunk's copy with another's kernel and the channels are long; bands end on multiples
+// of 32 rows (whole 128-byte lines of the device array) and are about 32 MiB each.
 static size_t band_rows_of(const ChunkPlan &plan, const Shape &j, size_t row_bytes)
 {
   size_t band_bytes = (size_t)32 << 20, min_T = 4096;
@@ -571,7 +579,7 @@ struct EncChunk
   int slot = 0;
   uint64_t total = 0; // packed bytes of the chunk
   bool gathered = false, redone = false;
-  bool bands = false; // its rows went up in bands beside the running kernel
+  bool bands = false; // its rows went up in bands, each coded by a launch of its own
   std::vector<uint8_t> redo_bytes; // a chunk that needed worst-case slabs: its packed streams, already on the host
 };
 
@@ -667,7 +675,7 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     cj.C = ch.n;
     cj.ld = ch.n;
     const uint8_t *const src = (const uint8_t *)samples + ch.c0 * esz;
-    const size_t band_rows = pl->bands_broken ? 0 : band_rows_of(plan, j, ch.n * esz);
+    const size_t band_rows = band_rows_of(plan, j, ch.n * esz);
     if (band_rows == 0)
     {
       HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, src, j.ld * esz, ch.n * esz, j.T, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
@@ -677,34 +685,40 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     else
     {
       // Few, long channels: a channel's serial chain takes the same kernel time however few channels there are, so
-      // upload and kernel of the (only) chunk must not take turns.  The kernel starts at once and its filling waves take
-      // rows as they arrive: the rows go up in bands on a second stream, each followed by the new value of the progress
-      // word the kernel polls (EncodeArgs::rows_ready).
+      // upload and kernel of the (only) chunk must not take turns.  The rows go up in bands on a second stream, and every
+      // band is coded by a launch of its own that waits for nothing but its band's event: each launch takes the lanes'
+      // state where the one before left it (EncodeArgs::seg_state), the last one ends the streams.
       if (sl.s2 == nullptr)
         HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.s2, hipStreamNonBlocking), DEGA_ERROR_LIBRARY_CALL);
+      if (sl.reuse_ev == nullptr)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&sl.reuse_ev, hipEventDisableTiming), DEGA_ERROR_LIBRARY_CALL);
       const size_t nbands = (j.T + band_rows - 1) / band_rows;
-      HIP_TRY(ctx, sl.progress.need(256), DEGA_ERROR_MEMORY);
-      HIP_TRY(ctx, sl.progress_values.need(sizeof(uint32_t) * (nbands + 1)), DEGA_ERROR_MEMORY);
-      uint32_t *const values = (uint32_t *)sl.progress_values.p;
-      // The word starts at 0 -- written here and now (the slot is idle), not by a command on a stream: the copies' stream
-      // must depend on nothing that is queued behind a kernel, or a hardware queue shared between streams could hold the
-      // copies back behind the very kernel that waits for them.
-      values[nbands] = 0;
-      HIP_TRY(ctx, hipMemcpy(sl.progress.p, &values[nbands], sizeof(uint32_t), hipMemcpyHostToDevice), DEGA_ERROR_LIBRARY_CALL);
-      if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s, (const uint32_t *)sl.progress.p)) != DEGA_OK)
-        return r;
+      while (sl.band_ev.size() < nbands)
+      {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), DEGA_ERROR_LIBRARY_CALL);
+        sl.band_ev.push_back(e);
+      }
+      HIP_TRY(ctx, sl.seg_state.need((size_t)ENC_STATE_WORDS * ch.n * sizeof(uint32_t)), DEGA_ERROR_MEMORY);
+      // the slot's buffers may still be read by what its previous chunk left on the slot's stream (gather, download):
+      // the copies start behind that
+      HIP_TRY(ctx, hipEventRecord(sl.reuse_ev, sl.s), DEGA_ERROR_LIBRARY_CALL);
+      HIP_TRY(ctx, hipStreamWaitEvent(sl.s2, sl.reuse_ev, 0), DEGA_ERROR_LIBRARY_CALL);
       for (size_t b = 0; b < nbands; b++)
       {
         const size_t t0 = b * band_rows, t1 = std::min(j.T, t0 + band_rows);
-        HIP_TRY(ctx, rows_to_device(pl, sl.s2, (uint8_t *)sl.a.p + t0 * ch.n * esz, src + t0 * j.ld * esz, j.ld * esz, ch.n * esz, t1 - t0, samples_pinned),
-                DEGA_ERROR_LIBRARY_CALL);
-        values[b] = (uint32_t)t1;
-        HIP_TRY(ctx, hipMemcpyAsync(sl.progress.p, &values[b], sizeof(uint32_t), hipMemcpyHostToDevice, sl.s2), DEGA_ERROR_LIBRARY_CALL);
+        uint8_t *const dev_rows = (uint8_t *)sl.a.p + t0 * ch.n * esz;
+        HIP_TRY(ctx, rows_to_device(pl, sl.s2, dev_rows, src + t0 * j.ld * esz, j.ld * esz, ch.n * esz, t1 - t0, samples_pinned), DEGA_ERROR_LIBRARY_CALL);
+        HIP_TRY(ctx, hipEventRecord(sl.band_ev[b], sl.s2), DEGA_ERROR_LIBRARY_CALL);
+        HIP_TRY(ctx, hipStreamWaitEvent(sl.s, sl.band_ev[b], 0), DEGA_ERROR_LIBRARY_CALL);
+        Shape bj = cj;
+        bj.T = t1 - t0;
+        const uint32_t flags = (b > 0 ? ENC_SEG_CONTINUES : 0u) | (b + 1 < nbands ? ENC_SEG_MORE : 0u);
+        if ((r = launch_encode(ctx, dev_rows, bj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s, (uint32_t *)sl.seg_state.p, flags)) != DEGA_OK)
+          return r;
       }
-      TRACE("chunk %zu: %zu bands of %zu rows beside the kernel", k, nbands, band_rows);
-      ch.bands = true; // (what follows the kernel on its stream is enqueued in stage 2, when the copies are through:
-                       //  nothing waits in a queue behind the kernel while it waits for rows)
-      return DEGA_OK;
+      TRACE("chunk %zu: %zu bands of %zu rows, one launch each", k, nbands, band_rows);
+      ch.bands = true;
     }
     hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
     HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
@@ -719,36 +733,7 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
     Slot &sl = pl->slot[ch.slot];
     TRACE("chunk %zu stage2 wait", k);
     MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
-    if (ch.bands)
-    {
-      HIP_TRY(ctx, hipStreamSynchronize(sl.s2), DEGA_ERROR_LIBRARY_CALL); // every row is on the device
-      hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
-      HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-      HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, MetaView::bytes(ch.n), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
-    }
     HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
-    if (ch.bands)
-    {
-      // a kernel that stopped seeing rows arrive gives up after a few seconds (ENC_ROWS_POLLS) and says so: the chunk is
-      // done again the plain way, and this context uploads no more batches in bands
-      bool lost = false;
-      for (size_t i = 0; i < ch.n && !lost; i++)
-        lost = hm.err[i] == DEGA_ERROR_LIBRARY_CALL;
-      if (lost)
-      {
-        pl->bands_broken = true;
-        Shape cj = j;
-        cj.C = ch.n;
-        cj.ld = ch.n;
-        int r;
-        if ((r = launch_encode(ctx, sl.a.p, cj, j.C, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s)) != DEGA_OK)
-          return r;
-        hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
-        HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
-        HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, MetaView::bytes(ch.n), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
-        HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
-      }
-    }
     TRACE("chunk %zu sizes on the host", k);
     bool too_small = false;
     if (cap < worst_cap(j))

@@ -105,6 +105,28 @@ extern "C" __attribute__((visibility("default"))) int sim_synth(int32_t *x, size
   return 0;
 }
 
+
+// the channels' rows coded over several launches (rows [cuts[k], cuts[k+1]) each), the lanes' state saved in between
+extern "C" __attribute__((visibility("default"))) int sim_encode_segments(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, const size_t *cuts, int ncuts, uint8_t *out,
+                                                                       size_t cap, uint64_t *bits, int32_t *err)
+{
+  static const std::vector<uint32_t> tab = make_table();
+  std::vector<uint32_t> state(ENC_STATE_WORDS * C, 0xDEADBEEFu);
+  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS));
+  for (int k = 0; k + 1 < ncuts; k++)
+  {
+    EncodeArgs a{x + cuts[k] * ld, C, cuts[k + 1] - cuts[k], ld, out, cap, bits, err, tab.data(), 32u};
+    a.seg_state = state.data();
+    a.seg_flags = (k > 0 ? ENC_SEG_CONTINUES : 0u) | (k + 2 < ncuts ? ENC_SEG_MORE : 0u);
+    if (adaptive)
+      sim::launch(dega_encode_kernel<true>, grid, dim3(ENC_BLOCK), a);
+    else
+      sim::launch(dega_encode_kernel<false>, grid, dim3(ENC_BLOCK), a);
+  }
+  (void)T;
+  return 0;
+}
+
 // ---- direct test of the encoder's word paths against its bit-at-a-time path, on random (and nasty) states ------------
 #include <random>
 #include <stdio.h>
@@ -117,15 +139,17 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
   static const std::vector<uint32_t> tab = make_table();
   std::mt19937_64 rng(seed);
   int bad = 0;
+  constexpr uint32_t RAWT = 128; // a raw "ring" that holds everything a word can produce: the writer runs afterwards
   for (int r = 0; r < rounds; r++)
   {
     std::vector<uint32_t> buf_a(64), buf_b(64);
     const bool nasty = (rng() % 4) == 0;
     for (int i = 0; i < 64; i++)
       buf_a[i] = buf_b[i] = (nasty && (rng() % 4)) ? 0xFFFFFFFFu : (uint32_t)rng();
-    std::vector<uint32_t> ring_a(ENC_ORING * 64), ring_b(ENC_ORING * 64);
-    BacEncoder<ADAPTIVE> e;
-    e.init(buf_a.data(), 64, ring_a.data());
+    std::vector<uint32_t> ring_a(ENC_ORING * 64), ring_b(ENC_ORING * 64), raw_a(RAWT * 64), raw_b(RAWT * 64);
+    uint32_t nothing_absorbed = 0;
+    BacCoder<ADAPTIVE, RAWT> e;
+    e.init(raw_a.data(), &nothing_absorbed);
     // a normalised interval: start < H <= end and not (start >= Q and end < 3Q)
     uint32_t s, en;
     do
@@ -155,14 +179,19 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
       } while (e.c1 < 2 && e.tot < 3);
       e.mps = (uint32_t)(rng() & 1);
     }
-    e.fcnt = (uint32_t)(rng() % 32u);
-    e.F = (nasty ? ~(uint64_t)0 : rng()) & (((uint64_t)1 << e.fcnt) - 1);
-    e.prev = nasty ? 0xFFFFFFFFu - (uint32_t)(rng() % 2) : (uint32_t)rng();
-    e.pos = 1 + (uint32_t)(rng() % 40u);
-    e.drained = e.pos - 1;
-    BacEncoder<ADAPTIVE> f = e;
-    f.dst = buf_b.data();
-    f.oring = ring_b.data();
+    // the writer's side of the lane: bits waiting in F, a held-back word that may be all ones, words already stored
+    BacWriter<> we;
+    we.init(buf_a.data(), 64, ring_a.data());
+    we.fcnt = (uint32_t)(rng() % 32u);
+    we.F = (nasty ? ~(uint64_t)0 : rng()) & (((uint64_t)1 << we.fcnt) - 1);
+    we.prev = nasty ? 0xFFFFFFFFu - (uint32_t)(rng() % 2) : (uint32_t)rng();
+    we.pos = 1 + (uint32_t)(rng() % 40u);
+    we.drained = we.pos - 1;
+    BacWriter<> wf = we;
+    wf.dst = buf_b.data();
+    wf.oring = ring_b.data();
+    BacCoder<ADAPTIVE, RAWT> f = e;
+    f.raw = raw_b.data();
     // the rare symbol really is rare in most words of the skewed states, frequent in the others
     uint32_t word = (rng() % 3) ? (uint32_t)rng() : (uint32_t)(rng() & rng() & rng());
     if ((rng() % 6) == 0)
@@ -172,6 +201,7 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
     // (a) bit at a time
     for (uint32_t i = 0; i < 32; i++)
       e.encode_bit((word >> (31u - i)) & 1u, tab.data());
+    e.end_bits_word();
     // (b) the word path of the lane's class -- or, two rounds out of three, of a more general class, as happens when
     //     another lane of the wave needs one
     f.classify();
@@ -193,12 +223,7 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
         {
           uint32_t Mg[32];
           f.fetch_magics_first(tab.data(), Mg);
-          const uint32_t record = f.template encode_word<false, 8, true>(word, tab.data(), Mg);
-          if (record != 0)
-          {
-            (*ripples)++;
-            f.settle_word(record, 4);
-          }
+          f.template encode_word<false, 8, true>(word, tab.data(), Mg);
           if (f.after_part(word))
             break;
         }
@@ -208,50 +233,54 @@ static int fast_vs_slow(uint64_t seed, int rounds, int *word_taken, int *ripples
     {
       for (uint32_t i = 0; i < 32; i++)
         f.encode_bit((word >> (31u - i)) & 1u, tab.data());
+      f.end_bits_word();
     }
     else
     {
       (*word_taken)++;
       uint32_t Mg[32];
       f.fetch_magics_first(tab.data(), Mg);
-      uint32_t record = 0, groups = 8;
       if (cls == CLS_FAST8)
-      {
-        record = f.template encode_word<false, 8>(word, tab.data(), Mg);
-        groups = 4;
-      }
+        f.template encode_word<false, 8>(word, tab.data(), Mg);
       else if (cls == CLS_FAST4)
-        record = f.template encode_word<false, 4>(word, tab.data(), Mg);
+        f.template encode_word<false, 4>(word, tab.data(), Mg);
       else if constexpr (ADAPTIVE)
-        record = f.template encode_word<true, 4>(word, tab.data(), Mg);
-      if (record != 0)
-      {
-        (*ripples)++;
-        f.settle_word(record, groups);
-      }
+        f.template encode_word<true, 4>(word, tab.data(), Mg);
     }
+    // the writers absorb what the two coders dumped; a carry past the held-back word ripples into the stored words
+    const uint32_t before_a = buf_a[we.pos >= 2 ? we.pos - 2 : 0], before_b = before_a;
+    for (uint32_t k = 0; k < e.rwr; k++)
+      we.absorb(raw_a[(k % RAWT) * 64u]);
+    for (uint32_t k = 0; k < f.rwr; k++)
+      wf.absorb(raw_b[(k % RAWT) * 64u]);
+    (void)before_b;
     // Bring both to the same representation -- a carry may still wait above F's bits where the other path has already
     // added it to the held-back word (the same number either way) -- flush, and compare everything observable
-    for (BacEncoder<ADAPTIVE> *p : {&e, &f})
+    for (BacWriter<> *p : {&we, &wf})
     {
       const uint32_t carry = (uint32_t)(p->F >> p->fcnt);
       p->F &= ((uint64_t)1 << p->fcnt) - 1;
       const uint32_t sum = p->prev + carry;
       if (sum < carry)
+      {
+        (*ripples)++;
         p->ripple_carry_from(p->pos - 1u);
+      }
       p->prev = sum;
     }
-    e.drain_lane();
-    f.drain_lane();
-    const bool same = e.L == f.L && e.B == f.B && e.c1 == f.c1 && e.tot == f.tot && e.mps == f.mps && e.F == f.F && e.fcnt == f.fcnt &&
-                      e.prev == f.prev && e.pos == f.pos && e.drained == f.drained && e.err == f.err && buf_a == buf_b;
+    we.drain_lane();
+    wf.drain_lane();
+    if (buf_a[we.pos >= 2 ? we.pos - 2 : 0] != before_a)
+      (*ripples)++;
+    const bool same = e.L == f.L && e.B == f.B && e.c1 == f.c1 && e.tot == f.tot && e.mps == f.mps && we.F == wf.F && we.fcnt == wf.fcnt &&
+                      we.prev == wf.prev && we.pos == wf.pos && we.drained == wf.drained && we.err == wf.err && buf_a == buf_b && (f.rwr & 3u) == 0u;
     if (!same)
     {
       bad++;
       if (bad <= 6 && getenv("DEGA_SIM_VERBOSE") != nullptr)
-        fprintf(stderr, "round %d cls %u nasty %d: L %d B %d c1 %d tot %d mps %d F %d (%llx %llx) fcnt %d (%u %u) prev %d (%x %x) pos %d (%u %u) drained %d err %d buf %d\n", r, cls,
-                (int)nasty, e.L == f.L, e.B == f.B, e.c1 == f.c1, e.tot == f.tot, e.mps == f.mps, e.F == f.F, (unsigned long long)e.F, (unsigned long long)f.F,
-                e.fcnt == f.fcnt, e.fcnt, f.fcnt, e.prev == f.prev, e.prev, f.prev, e.pos == f.pos, e.pos, f.pos, e.drained == f.drained, e.err == f.err, buf_a == buf_b);
+        fprintf(stderr, "round %d cls %u nasty %d: L %d B %d c1 %d tot %d mps %d F %d (%llx %llx) fcnt %d (%u %u) prev %d (%x %x) pos %d (%u %u) drained %d err %d buf %d rwr %u\n", r, cls,
+                (int)nasty, e.L == f.L, e.B == f.B, e.c1 == f.c1, e.tot == f.tot, e.mps == f.mps, we.F == wf.F, (unsigned long long)we.F, (unsigned long long)wf.F,
+                we.fcnt == wf.fcnt, we.fcnt, wf.fcnt, we.prev == wf.prev, we.prev, wf.prev, we.pos == wf.pos, we.pos, wf.pos, we.drained == wf.drained, we.err == wf.err, buf_a == buf_b, f.rwr);
     }
   }
   return bad;
@@ -290,11 +319,11 @@ extern "C" __attribute__((visibility("default"))) int sim_encode_wide(const int3
 {
   static const std::vector<uint32_t> tab = make_table();
   EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), 32u};
-  const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 4 rows per batch, 16 / 24 ring words
+  const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 4 rows per batch, 16 / 8 / 16 ring slots
   if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 4, 16, 24, false, false, 8>, grid, dim3(1024), a);
+    sim::launch(dega_encode_kernel<true, false, 4, 16, 8, 16, false, false, 8, false>, grid, dim3(1024), a);
   else
-    sim::launch(dega_encode_kernel<false, false, 4, 16, 24, false, false, 8>, grid, dim3(1024), a);
+    sim::launch(dega_encode_kernel<false, false, 4, 16, 8, 16, false, false, 8, false>, grid, dim3(1024), a);
   return 0;
 }
 
@@ -317,9 +346,9 @@ extern "C" __attribute__((visibility("default"))) int sim_encode64(const int64_t
   EncodeArgs a{reinterpret_cast<const int32_t *>(x), C, T, ld, out, cap, bits, err, tab.data(), (uint32_t)valuesize};
   const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS));
   if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 4, 32, 32, true>, grid, dim3(ENC_BLOCK), a);
+    sim::launch(dega_encode_kernel<true, false, 4, 32, 16, 32, true>, grid, dim3(ENC_BLOCK), a);
   else
-    sim::launch(dega_encode_kernel<false, false, 4, 32, 32, true>, grid, dim3(ENC_BLOCK), a);
+    sim::launch(dega_encode_kernel<false, false, 4, 32, 16, 32, true>, grid, dim3(ENC_BLOCK), a);
   return 0;
 }
 

@@ -170,3 +170,30 @@ def test_long_channels_halvings_and_rare_symbol_runs(sim):
     derr = np.zeros(Cn, dtype=np.int32)
     sim.sim_decode(out.ctypes.data, out.shape[1], bits.ctypes.data, Cn, T, Cn, 1, y.ctypes.data, derr.ctypes.data)
     assert (derr == 0).all() and (y == x).all()
+
+
+def test_channels_coded_over_several_launches_with_saved_state(sim):
+    """The rows of a batch coded in ranges, one launch per range, every lane's state (bit queue, interval, model, finished
+    bits, held-back word) saved in between (EncodeArgs::seg_state): the streams must be those of one launch -- cuts inside a
+    seg-bit word, right after the first row, ranges of a single row, an empty last range, channels in error."""
+    sim.sim_encode_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    T, Cn = 700, 130  # a ragged last wave
+    x = (np.cumsum(rng.integers(-300, 301, (T, Cn)), axis=0) + 70000).astype(np.int32)
+    x[300:, 7] = -5  # a channel that goes out of range in the middle (diff.c:17-18)
+    x[0, 9] = -1     # ... and one that starts out of range
+    cap = (orc.lib().orc_dega_worst_case_bytes(T) + 3) & ~3
+    for ad in (1, 0):
+        want_out, want_bits, want_err = orc.encode_batch_tc(x, ad, cap=cap)
+        for cuts in ([0, 1, 2, 350, 351, 699, 700], [0, 255, 700, 700], [0, 8, 16, 400, 700]):
+            out = np.zeros((Cn, cap), dtype=np.uint8)
+            bits = np.zeros(Cn, dtype=np.uint64)
+            err = np.zeros(Cn, dtype=np.int32)
+            cu = np.array(cuts, dtype=np.uint64)
+            sim.sim_encode_segments(x.ctypes.data, Cn, T, Cn, ad, cu.ctypes.data, len(cuts), out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+            assert (err == want_err).all(), (ad, cuts)
+            ok = want_err == 0
+            assert (bits[ok] == want_bits[ok]).all(), (ad, cuts)
+            for c in np.nonzero(ok)[0]:
+                nb = (int(want_bits[c]) + 7) // 8
+                assert out[c, :nb].tobytes() == want_out[c, :nb].tobytes(), (ad, cuts, c)

@@ -23,9 +23,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     res = {"lib": os.path.basename(dca.LIB_PATH), "kernel_ms": round(ms, 4), "bits_per_sample": round(float(bits.sum()) / (C_ * T), 3)}
     if "diag32" in dca.LIB_PATH:
         b = bits.cpu().numpy().reshape(-1, 64)
-        names = ["publish", "general_or_fast4_word", "loads+ballot_has", "fast8_word", "masked_fast8_word", "bit_word", "drain", "loop_top"]
-        res["cycles_per_wave"] = {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in range(8)}
-        res["total_cycles"] = int(b[:, :8].sum(axis=1).mean())
+        names = ["steady_steps", "steady_masked_steps", "other_word_steps", "waits"]
+        res["coder_passes_per_wave"] = {names[k]: {"count": int(b[:, k].mean()), "cycles": int(b[:, 4 + k].mean())} for k in range(4)}
+        res["total_cycles"] = int(b[:, 4:8].sum(axis=1).mean())
     print(json.dumps(res))
     if len(sys.argv) > 4 and sys.argv[4] == "decode":
         y = torch.zeros((T, C_), dtype=torch.int32, device="cuda"); derr = torch.zeros(C_, dtype=torch.int32, device="cuda")

@@ -19,11 +19,19 @@ passes() {  # $1 = name, rest = program
     rocprofv3 --pmc LDSBankConflict MeanOccupancyPerCU --output-format csv -d $O/${n}_lds -- "$@" > $O/${n}_lds.log 2>&1
     rocprofv3 --pmc $SQ --output-format csv -d $O/${n}_sq -- "$@" > $O/${n}_sq.log 2>&1
 }
+quick() {  # $1 = name, rest = program: kernel stats + the instruction-mix pass only
+    n=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/${n}_stats -- "$@" > $O/${n}_stats.log 2>&1
+    rocprofv3 --pmc $SQ --output-format csv -d $O/${n}_sq -- "$@" > $O/${n}_sq.log 2>&1
+    rocprofv3 --pmc VALUBusy SALUBusy --output-format csv -d $O/${n}_valu -- "$@" > $O/${n}_valu.log 2>&1
+}
 COMMON="--cpu-channels 0 --no-extras --end-to-end-channels 0"
 for s in $SECTIONS; do
     case $s in
     dega) passes dega python3 $R/bench.py --steps 3 --warmup 1 $COMMON ;;
     cfg3) passes cfg3 python3 $R/bench.py --steps 3 --warmup 1 --channels 1048576 --samples 96 --step-size 300 $COMMON ;;
+    dega_quick) quick dega python3 $R/bench.py --steps 3 --warmup 1 $COMMON ;;
+    lzmh_quick) quick lzmh python3 $R/bench.py --workload lzmh --steps 2 --warmup 1 $COMMON ;;
     lzmh) passes lzmh python3 $R/bench.py --workload lzmh --steps 2 --warmup 1 $COMMON ;;
     esac
 done
