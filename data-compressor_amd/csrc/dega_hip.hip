@@ -278,13 +278,10 @@ static int check_job_shape(dega_hip_ctx *ctx, const Shape &j, size_t cap)
 }
 
 template <bool AD, bool NARROW, bool F32>
-static void encode_launch(bool wide, size_t C, hipStream_t s, const EncodeArgs &a)
+static void encode_launch(size_t C, hipStream_t s, const EncodeArgs &a)
 {
-  if (wide) // more channels than one coding wave per SIMD: 8 pairs of waves per workgroup, smaller rings
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 4, 16, 8, 16, false, F32, 8, false>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
-  else
-    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_RAW, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
-                       dim3(ENC_BLOCK), 0, s, a);
+  hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_RAW, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
+                     dim3(ENC_BLOCK), 0, s, a);
 }
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)
@@ -317,7 +314,7 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
   a.lo = -(float)((uint64_t)1 << (vs - 1));
   a.hi = (float)(((uint64_t)1 << (vs - 1)) - 1);
   const bool f32 = j.samples == DEGA_SAMPLES_F32, ad = j.adaptive != 0;
-  const bool wide = ctx->force_waves == 8 || (ctx->force_waves == 0 && batch_C > 65536);
+  (void)batch_C; // (one workgroup shape for every batch size)
   {
     LaunchTimer lt(ctx, 0, s);
     if (vs > 32) // 64-bit values
@@ -341,14 +338,14 @@ static int launch_encode(dega_hip_ctx *ctx, const void *x, const Shape &j, size_
       const int sel = (ad ? 4 : 0) | (narrow ? 2 : 0) | (f32 ? 1 : 0);
       switch (sel)
       {
-        case 0: encode_launch<false, false, false>(wide, j.C, s, a); break;
-        case 1: encode_launch<false, false, true>(wide, j.C, s, a); break;
-        case 2: encode_launch<false, true, false>(wide, j.C, s, a); break;
-        case 3: encode_launch<false, true, true>(wide, j.C, s, a); break;
-        case 4: encode_launch<true, false, false>(wide, j.C, s, a); break;
-        case 5: encode_launch<true, false, true>(wide, j.C, s, a); break;
-        case 6: encode_launch<true, true, false>(wide, j.C, s, a); break;
-        default: encode_launch<true, true, true>(wide, j.C, s, a); break;
+        case 0: encode_launch<false, false, false>(j.C, s, a); break;
+        case 1: encode_launch<false, false, true>(j.C, s, a); break;
+        case 2: encode_launch<false, true, false>(j.C, s, a); break;
+        case 3: encode_launch<false, true, true>(j.C, s, a); break;
+        case 4: encode_launch<true, false, false>(j.C, s, a); break;
+        case 5: encode_launch<true, false, true>(j.C, s, a); break;
+        case 6: encode_launch<true, true, false>(j.C, s, a); break;
+        default: encode_launch<true, true, true>(j.C, s, a); break;
       }
     }
   }
@@ -360,7 +357,7 @@ template <bool AD, bool NARROW, bool F32>
 static void decode_launch(bool wide, size_t C, hipStream_t s, const DecodeArgs &a)
 {
   if (wide)
-    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32, 8>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32, 8, false>), dim3((unsigned)((C + 511) / 512)), dim3(1024), 0, s, a);
   else
     hipLaunchKernelGGL((dega_decode_kernel<AD, NARROW, false, F32>), dim3((unsigned)((C + DEC_CHANNELS - 1) / DEC_CHANNELS)), dim3(DEC_BLOCK), 0, s, a);
 }

@@ -109,18 +109,23 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
   __syncthreads();
 }
 
-// One workgroup = PAIRS pairs of waves = PAIRS * 64 channels.  Of each pair (wave p and wave p + PAIRS: the CU deals a
-// workgroup's waves out to its four SIMDs in turn, so the two share a SIMD) the second CODES -- seg-bit words through the
-// arithmetic coder, nothing else -- and the first HELPS: it fills (rows in, normalize, diff, seg -> bit words into the
-// lane's column of an LDS ring) and it writes (the coder's raw entries -> 32-bit words -> the slab).
-// A channel's coder is serial and bound by the instructions of ITS wave: one wave issues an instruction every 4.1 - 4.6
-// cycles whatever shares the SIMD with it, while two waves together get ~3.2 cycles per instruction out of the SIMD and
-// four ~2.5 (profiles/r03_ubench2_issue_cost.txt).  64 Ki channels are one coding wave per SIMD: every instruction that is
-// not the arithmetic itself is worth moving into the partner, whose instructions go into issue slots the coder cannot use.
-// The two talk through one published word per lane and direction (peer_store / peer_load); a wave with nothing to do sleeps.
-//   helper publishes: ring words written (mod 2^16) | raw entries absorbed (mod 2^8) << 16 | all rows done << 24 |
+// 64 channels are the work of THREE waves that the CU places on the same SIMD (waves g, g + 4, g + 8 of a workgroup of
+// twelve):
+//   the coding wave   seg-bit words through the arithmetic coder, nothing else;
+//   the filling wave  rows in (LDS-DMA), normalize, diff, seg -> bit words into the lane's column of an LDS ring;
+//   the writing wave  the coder's raw entries -> 32-bit words -> the slab.
+// A channel's coder is serial, and what bounds it is the instruction stream of ITS wave: one wave issues an instruction
+// every 4.1 - 4.6 cycles whatever shares the SIMD with it, while two waves together get ~3.2 cycles per instruction out of
+// the SIMD, three ~2.9, four ~2.5 (profiles/r03_ubench2_issue_cost.txt).  64 Ki channels are one coding wave per SIMD:
+// every instruction that is not the arithmetic itself is worth moving into a helper, whose instructions go into issue
+// slots the coder cannot use -- up to the point where the SIMD as a whole is full, which is where the kernel is now
+// (VALUBusy 100 %: every helper instruction costs the coder a little).
+// The waves talk through one published word per lane each (peer_store / peer_load); a wave with nothing to do sleeps.
+//   filler publishes: ring words written (mod 2^16) | all rows done << 24 | a value was out of range << 25 |
 //                     bits of the final, partial word << 27
-//   coder publishes:  ring words consumed (mod 2^16) | raw entries written (mod 2^8) << 16 | all entries written << 24
+//   writer publishes: raw entries absorbed (mod 2^8) << 16
+//   coder publishes:  ring words consumed (mod 2^16) | raw entries written (mod 2^8) << 16 | all entries written << 24 |
+//                     the filler's verdict << 25
 // ROWS rows per fill batch; RING / RAW / ORING: seg-bit words, raw entries, staged output words per lane.
 // W64: valuesize 33..64 -- a.x is int64 [T][ld]; rows travel as two dwords per lane, the fill step takes the general
 // writer (127-bit worst-case codewords), everything behind the bit queue is the same.  Instantiated with ROWS = 4.
@@ -153,26 +158,29 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 #ifndef DG_DEC_CODE_SLEEP
 #define DG_DEC_CODE_SLEEP 1
 #endif
+#ifndef DG_DEC_LOAD_SLEEP
+#define DG_DEC_LOAD_SLEEP 8
+#endif
 #ifndef DG_DEC_CODE_PRIO
 #define DG_DEC_CODE_PRIO 0
 #endif
 #ifndef DG_DEC_TAKES // unconditional short-codeword takes per pass of the parsing wave
 #define DG_DEC_TAKES 4
 #endif
-constexpr uint32_t ENC_PAIRS = 4;
-constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 192;   // threads per workgroup (narrow batches: a filling, a coding and a writing wave per 64 channels)
+constexpr uint32_t ENC_PAIRS = 4;                 // groups of three waves per workgroup
+constexpr uint32_t ENC_BLOCK = ENC_PAIRS * 192;   // threads per workgroup: a filling, a coding and a writing wave per 64 channels
 constexpr uint32_t ENC_CHANNELS = ENC_PAIRS * 64; // channels per workgroup
 constexpr uint32_t ENC_PUB_DONE = 1u << 24, ENC_PUB_BAD = 1u << 25;
 
 // ---- the helping wave(s): fill and write -------------------------------------------------------------------------------
-// FILLS / WRITES: both in one wave (batches of more than 64 Ki channels: two coding waves per SIMD cover for each other
-// when a helper is late), or a wave each (up to 64 Ki channels: the one coding wave of a SIMD must never wait, and three
-// waves get more instructions per cycle out of a SIMD than two).
+// FILLS / WRITES: which of the two this wave is.  (A wave each: the coding wave of a SIMD must never wait for either, and
+// three waves get more instructions per cycle out of a SIMD than two -- one wave doing both left the coder waiting for
+// room a sixth of its time.)
 template <bool NARROW, uint32_t ROWS, uint32_t RING, uint32_t RAW, uint32_t ORING, bool W64, bool F32IN, bool FILLS, bool WRITES>
 DG_DEV void encode_helping_wave(const EncodeArgs &a, uint32_t *ring_col, const uint32_t *raw_col, uint32_t *oring_col, uint32_t *rows_wave, uint32_t *pub_mine,
                                 const uint32_t *pub_peer, uint32_t lane, size_t c, bool live, size_t c_wave0)
 {
-  static_assert(FILLS || WRITES, "a helper with nothing to do");
+  static_assert(FILLS != WRITES, "a helper fills or writes");
   // NARROW: valuesize < 32 -- the samples are masked to valuesize bits and the difference is range checked against it
   constexpr uint32_t FILL_WORDS = (31 + (W64 ? 127 : 65) * ROWS) / 32; // most words a batch can add (worst-case codewords)
   constexpr bool ROWS64 = W64 && !F32IN; // rows of two dwords per lane
@@ -369,7 +377,7 @@ DG_DEV void encode_helping_wave(const EncodeArgs &a, uint32_t *ring_col, const u
     t += left < ROWS ? left : ROWS;
   };
 
-  wave_priority<(FILLS ? DG_ENC_FILL_PRIO : DG_ENC_WRITE_PRIO)>();
+  wave_priority<(WRITES ? DG_ENC_WRITE_PRIO : DG_ENC_FILL_PRIO)>();
   if (FILLS && a.T > 0)
     issue_rows(0);
   bool tail_placed = !FILLS; // the final, partial word is in the ring (or stays in the state) and "done" is published
@@ -547,8 +555,7 @@ DG_DEV void encode_helping_wave(const EncodeArgs &a, uint32_t *ring_col, const u
 }
 
 // ---- the coding wave -------------------------------------------------------------------------------------------------
-// SPLIT: filler and writer are two waves with a published word each (else: one wave, one word)
-template <bool ADAPTIVE, uint32_t RING, uint32_t RAW, bool SPLIT>
+template <bool ADAPTIVE, uint32_t RING, uint32_t RAW>
 DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const uint32_t *ring_col, uint32_t *raw_col, uint32_t *pub_mine, const uint32_t *pub_peer,
                                const uint32_t *pub_writer, uint32_t lane, size_t c, bool live)
 {
@@ -569,9 +576,10 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
   // The helper's word as read one step ago: a ring word may only be read after a count that covers it, and waiting for
   // the count before asking for the word would put two LDS round trips at the head of every step.  One step late costs
   // nothing (the counts only grow, the ring holds a dozen words).
-  uint32_t peer = peer_load(pub_peer), peerw = SPLIT ? peer_load(pub_writer) : peer;
+  uint32_t peer = peer_load(pub_peer), peerw = peer_load(pub_writer);
   enc.classify(); // the class of the first word
   wave_priority<DG_ENC_CODE_PRIO>();
+  bool waiting = false; // (wave uniform) at low priority, nothing to do
 #if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
   // diagnostic build: what the coding wave's passes were (steady / steady masked / other word paths / nothing to do: no word, no room), in cycles too
   uint64_t dg_n[4] = {0, 0, 0, 0}, dg_c[4] = {0, 0, 0, 0}, dg_t = __builtin_amdgcn_s_memtime();
@@ -593,13 +601,18 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     uint32_t Mg[32];
     enc.fetch_magics_first(tab, Mg);
     peer = peer_load(pub_peer);
-    peerw = SPLIT ? peer_load(pub_writer) : peer;
+    peerw = peer_load(pub_writer);
     // The steady state: every lane of the wave has a word, room for its four entries, and a fast class (every lane knows the
     // class of its NEXT word and for how many words it holds: BacCoder::classify, looked at again when the count has run out,
     // at the end of the step) -- one ballot, then straight-line code for all 64 lanes, no exec masks, no merges.
     const bool ready = has && room4;
     if (wave_all(ready && enc.cls == CLS_FAST8))
     {
+      if (waiting)
+      {
+        wave_priority<DG_ENC_CODE_PRIO>();
+        waiting = false;
+      }
       enc.template encode_word<false, 8>(word, tab, Mg);
       rd++;
       enc.safe--;
@@ -618,6 +631,11 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     {
       if (wave_all(ready && enc.cls <= CLS_SPLIT))
       {
+        if (waiting)
+        {
+          wave_priority<DG_ENC_CODE_PRIO>();
+          waiting = false;
+        }
         enc.template encode_word<false, 8, true>(word, tab, Mg);
         const bool whole = enc.cls != CLS_SPLIT || enc.after_part(word);
         rd += whole ? 1u : 0u;
@@ -641,9 +659,22 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
     {
       if (wave_all(all_done && !has))
         break; // all rows consumed and every queue drained ("done" comes in one word with the final count)
+      // Nothing to do until a helper has moved -- and the helpers need the SIMD's issue slots to move: a waiting wave that
+      // kept its priority would poll them out of the way (two coding waves on a SIMD, both waiting at priority 3, starved
+      // their helpers of every slot: a batch of 128 Ki channels took seconds)
+      if (!waiting)
+      {
+        wave_priority<0>();
+        waiting = true;
+      }
       wave_sleep<DG_ENC_CODE_SLEEP>();
       DG_COUNT(3);
       continue;
+    }
+    if (waiting)
+    {
+      wave_priority<DG_ENC_CODE_PRIO>();
+      waiting = false;
     }
     // Which word path?  The wave takes the most expensive class among its lanes.
     uint32_t cls = can ? enc.cls : CLS_FAST8;
@@ -737,66 +768,59 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
 #endif
 }
 
-// PAIRS: 4 groups of three waves (SPLIT: filler, coder, writer) for batches of up to 64 Ki channels -- one coding wave per
-// SIMD is all there is --; 8 pairs (coder + a helper that fills and writes), with the smaller rings <.., 4, 16, 8, 16, ..>,
-// for larger ones: two coding waves per SIMD, and half as many workgroups to load the table.
+// One workgroup = GROUPS groups of three waves (filler, coder, writer) = GROUPS * 64 channels sharing the table of division
+// magics: 4 groups = one coding wave per SIMD.  Batches of more than 64 Ki channels simply have more workgroups than the
+// chip holds at once (a workgroup takes a CU's LDS): measured, that beats packing two coding waves onto a SIMD with
+// smaller rings and one helper each (119 against 81 Gsamples/s on 128 Ki channels x 8 640).
 template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t RAW = ENC_RAW, uint32_t ORING = ENC_ORING, bool W64 = false,
-          bool F32IN = false, uint32_t PAIRS = ENC_PAIRS, bool SPLIT = true>
-__global__ void __launch_bounds__(PAIRS * (SPLIT ? 192 : 128)) dega_encode_kernel(const EncodeArgs a)
+          bool F32IN = false, uint32_t GROUPS = ENC_PAIRS>
+__global__ void __launch_bounds__(GROUPS * 192) dega_encode_kernel(const EncodeArgs a)
 {
   constexpr uint32_t LDS_ROWS = (W64 && !F32IN) ? 2 * ROWS : ROWS;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
   // access with a vmcnt(0) wait):  division magics (64 KiB) | per group: seg-bit ring, raw ring, staging ring, input rows,
   // the three published rows
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
-  constexpr uint32_t PER_PAIR = (RING + RAW + ORING + LDS_ROWS + 3) * 64;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + PAIRS * PER_PAIR];
+  constexpr uint32_t PER_GROUP = (RING + RAW + ORING + LDS_ROWS + 3) * 64;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + GROUPS * PER_GROUP];
   static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
   uint32_t *const tab = lds;
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = wave_uniform(threadIdx.x >> 6);
-  const uint32_t pair = wave % PAIRS;
-  // 0: fills (and writes, unless SPLIT), 1: codes, 2: writes.  Which wave of a group does what decides which is the oldest on
-  // its SIMD, and the oldest ready wave issues first when priorities tie (DG_ENC_ROLE_ORDER: measurement knob)
-#ifndef DG_ENC_ROLE_ORDER
-#define DG_ENC_ROLE_ORDER 0
-#endif
-  constexpr uint32_t role_of[4][3] = {{0, 1, 2}, {1, 2, 0}, {1, 0, 2}, {2, 1, 0}};
-  const uint32_t role = SPLIT ? role_of[DG_ENC_ROLE_ORDER][wave / PAIRS] : wave / PAIRS;
-  uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
-  uint32_t *const ring_col = pair_lds + lane;                              // seg bits waiting to be coded
-  uint32_t *const raw_col = pair_lds + RING * 64 + lane;                   // the coder's dumps waiting to be absorbed
-  uint32_t *const oring_col = pair_lds + (RING + RAW) * 64 + lane;         // coded words waiting to be stored
-  uint32_t *const rows_wave = pair_lds + (RING + RAW + ORING) * 64;        // the next input rows (wave uniform)
-  uint32_t *const pub_filler = pair_lds + (RING + RAW + ORING + LDS_ROWS) * 64 + lane;
+  const uint32_t group = wave % GROUPS;
+  // 0: fills, 1: codes, 2: writes -- waves g, g + GROUPS, g + 2 GROUPS of the workgroup: the CU deals a workgroup's waves out
+  // to its four SIMDs in turn, so the three share a SIMD.  (Which of them is the oldest there decides who issues first
+  // when priorities tie; the priorities are what matters: coder 3 > writer 1 > filler 0.)
+  const uint32_t role = wave / GROUPS;
+  uint32_t *const group_lds = lds + TAB_WORDS + group * PER_GROUP;
+  uint32_t *const ring_col = group_lds + lane;                              // seg bits waiting to be coded
+  uint32_t *const raw_col = group_lds + RING * 64 + lane;                   // the coder's dumps waiting to be absorbed
+  uint32_t *const oring_col = group_lds + (RING + RAW) * 64 + lane;         // coded words waiting to be stored
+  uint32_t *const rows_wave = group_lds + (RING + RAW + ORING) * 64;        // the next input rows (wave uniform)
+  uint32_t *const pub_filler = group_lds + (RING + RAW + ORING + LDS_ROWS) * 64 + lane;
   uint32_t *const pub_coder = pub_filler + 64;
-  uint32_t *const pub_writer = SPLIT ? pub_filler + 128 : pub_filler;
-  if (wave < PAIRS) // nothing written, nothing consumed, nothing absorbed
+  uint32_t *const pub_writer = pub_filler + 128;
+  if (role == 0) // nothing written, nothing consumed, nothing absorbed
   {
     *pub_filler = 0;
     *pub_coder = 0;
-    pub_filler[128] = 0;
+    *pub_writer = 0;
   }
   // (a launch that goes on from saved state may be anywhere in its channels' streams: the whole table)
   load_div_table<ADAPTIVE>(tab, a.div_magic, a.seg_state != nullptr ? ~0ull : (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
 
-  const size_t c_wave0 = (size_t)blockIdx.x * (PAIRS * 64u) + pair * 64u;
+  const size_t c_wave0 = (size_t)blockIdx.x * (GROUPS * 64u) + group * 64u;
   const size_t c = c_wave0 + lane;
   const bool live = c < a.C;
   if (!wave_any(live))
     return; // a group past the last channel
   if (role == 1)
-    encode_coding_wave<ADAPTIVE, RING, RAW, SPLIT>(a, tab, ring_col, raw_col, pub_coder, pub_filler, pub_writer, lane, c, live);
-  else if constexpr (SPLIT)
-  {
-    if (role == 0)
-      encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, true, false>(a, ring_col, raw_col, oring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
-    else
-      encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, false, true>(a, ring_col, raw_col, oring_col, rows_wave, pub_writer, pub_coder, lane, c, live, c_wave0);
-  }
+    encode_coding_wave<ADAPTIVE, RING, RAW>(a, tab, ring_col, raw_col, pub_coder, pub_filler, pub_writer, lane, c, live);
+  else if (role == 0)
+    encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, true, false>(a, ring_col, raw_col, oring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
   else
-    encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, true, true>(a, ring_col, raw_col, oring_col, rows_wave, pub_filler, pub_coder, lane, c, live, c_wave0);
+    encode_helping_wave<NARROW, ROWS, RING, RAW, ORING, W64, F32IN, false, true>(a, ring_col, raw_col, oring_col, rows_wave, pub_writer, pub_coder, lane, c, live, c_wave0);
 }
 
 // =====================================================================================================================
@@ -818,7 +842,7 @@ constexpr uint32_t DEC_IRING = 16;                 // staged stream words per la
 constexpr uint32_t DEC_BRING = 8;                  // decoded words in flight between the two waves, per lane
 constexpr uint32_t DEC_SRING = 16;                 // decoded samples per lane (the 64-bit variants)
 constexpr uint32_t DEC_PAIRS = 4;                  // pairs of waves per workgroup
-constexpr uint32_t DEC_BLOCK = DEC_PAIRS * 128;    // threads per workgroup
+constexpr uint32_t DEC_BLOCK = DEC_PAIRS * 192;    // threads per workgroup: a coding, a parsing and a loading wave per 64 channels
 constexpr uint32_t DEC_CHANNELS = DEC_PAIRS * 64;  // channels per workgroup
 
 // what the coding wave publishes: words handed over so far (mod 2^16) | valid bits of the LAST word if it is a partial
@@ -855,8 +879,11 @@ struct alignas(16) DecodeQuad
 // ---- the coding wave -------------------------------------------------------------------------------------------------
 // pair_lds: [DEC_IRING rows: the lane's stream words][4 rows: DMA landing area][DEC_BRING rows: decoded words]
 //           [1 row: published by this wave][1 row: published by the partner] ...
-template <bool ADAPTIVE>
-DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_t *pair_lds, uint32_t lane, size_t c, bool live)
+// SPLIT: the stream words are staged by a loading wave of their own (decode_loading_wave; `pub_loader` = its published
+// word: words staged so far, mod 2^16) and this wave has its steady paths; else it stages them itself, as the pairs of
+// the wide workgroups do.
+template <bool ADAPTIVE, bool SPLIT>
+DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_t *pair_lds, const uint32_t *pub_loader, uint32_t lane, size_t c, bool live)
 {
   uint32_t *const iring = pair_lds + lane;
   uint32_t *const stage_wave = pair_lds + DEC_IRING * 64;
@@ -879,8 +906,9 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
   BacDecoder<ADAPTIVE> dec;
   dec.init();
 
-  uint32_t in_loaded = 0;   // stream words staged so far (a multiple of 4; beyond the stream: zeros)
+  uint32_t in_loaded = 0;   // stream words staged so far (a multiple of 4; beyond the stream: zeros) -- SPLIT: as far as this wave has seen, see `ahead`
   bool requested = false;   // a group of 4 is on its way (or due as zeros)
+  bool slow_word = false;   // (SPLIT) the steady path gave this lane's word up: it goes bit by bit
   bool started = false;     // StartDecoding done
   bool bac_done = !live;    // EOF symbol seen, error, or the partner wants no more
   uint32_t seg_bits = 0;    // seg bits decoded so far
@@ -891,7 +919,10 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
     return; // a wave past the last channel
   wave_priority<DG_DEC_CODE_PRIO>();
 
-  auto request_refill = [&]() // 4 more words for every lane that has ring room for them
+  // SPLIT: the loader's count is known modulo 2^16; it never trails the words this wave has passed, and leads them by at
+  // most the ring: the difference is exact.  `in_loaded` is rebuilt from it at the top of every step.
+  auto loaded_from = [&](uint32_t loader_word) { return (uint32_t)(dec.bp >> 5) + ((loader_word - (uint32_t)(dec.bp >> 5)) & 0xFFFFu); };
+  [[maybe_unused]] auto request_refill = [&]() // 4 more words for every lane that has ring room for them
   {
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
     const bool want = live && !requested && !bac_done && in_loaded + 4u - k0 <= DEC_IRING;
@@ -909,12 +940,19 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
     }
     requested = requested || want;
   };
-  request_refill();
+  if constexpr (!SPLIT)
+    request_refill();
+  uint32_t loader_seen = SPLIT ? peer_load(pub_loader) : 0u;
+  auto publish = [&]() {
+    // (SPLIT: with the word this wave has reached, mod 64, for the loader: it stages at most a ring's worth ahead)
+    peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u) | (SPLIT ? ((uint32_t)(dec.bp >> 5) & 63u) << 26 : 0u));
+  };
+  dec.classify();
 
   for (;;)
   {
     // ---- what the step reads from LDS first: four stream words, the first quarter of the division magics, and how far
-    //      the partner has come; nothing LDS is carried around the loop
+    //      the partner(s) have come; nothing LDS is carried around the loop
     const uint32_t k0 = (uint32_t)(dec.bp >> 5);
     uint32_t pre[4], Mnext[32];
 #pragma unroll
@@ -922,6 +960,11 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
       pre[j] = in.word(k0 + j);
     dec.fetch_magics_first(tab, Mnext);
     const uint32_t peer = peer_load(pub_peer);
+    if constexpr (SPLIT)
+    {
+      in_loaded = loaded_from(loader_seen); // (the count as read one step ago: the words it covers may be read now)
+      loader_seen = peer_load(pub_loader);
+    }
     const bool input_ok = in_loaded >= k0 + 4u;
     if (live && !started && input_ok)
     {
@@ -933,6 +976,54 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
     const bool room = ((wr - peer) & 0xFFFFu) < DEC_BRING;
     const bool can = live && started && !bac_done && room;
     const bool can_word = can && input_ok && nacc == 0u;
+    if constexpr (SPLIT)
+    {
+      // The steady state: every lane of the wave can decode a whole word, and its class (BacDecoder::classify, looked at a
+      // step ahead) is a fast one -- one ballot, then straight-line code for all 64 lanes, no exec masks, no merges.  A
+      // word that does not come through (the EOF symbol is in it, or its symbols take more stream bits than the word path
+      // looks ahead) is given up: back to where the step began, and bit by bit in the general path below.
+      const bool ready = can_word && !slow_word;
+      const bool plain = wave_all(ready && dec.cls == DCLS_FAST);
+      if (plain || (ADAPTIVE && wave_all(ready && dec.cls <= DCLS_SPLIT)))
+      {
+        const BacDecoder<ADAPTIVE> checkpoint = dec;
+        uint32_t bits = 0;
+        bool done, whole = true;
+        if (plain)
+          done = dec.template decode_word<false>(tab, Mnext, pre, bits);
+        else
+        {
+          dec.begin_word();
+          done = dec.template decode_word<false, ADAPTIVE>(tab, Mnext, pre, bits);
+          if (done)
+            whole = dec.after_part(bits);
+        }
+        if (wave_any(!done))
+        {
+          if (!done)
+          {
+            dec = checkpoint;
+            nacc = dec.part_lo; // what a first part has decoded is kept as the beginning of the bit-by-bit word
+            acc = nacc != 0u ? dec.part_bits >> (32u - nacc) : 0u;
+            dec.whole_word();
+            slow_word = true;
+            whole = false;
+          }
+        }
+        bring[(wr % DEC_BRING) * 64u] = bits; // (harmless when the word is not whole: the slot is rewritten)
+        wr += whole ? 1u : 0u;
+        seg_bits += whole ? 32u : 0u;
+        dec.safe -= dec.safe != 0u ? 1u : 0u;
+        const bool again = done && whole && dec.safe == 0u;
+        if (wave_any(again))
+        {
+          if (again)
+            dec.classify();
+        }
+        publish();
+        continue;
+      }
+    }
     if (wave_any(can))
     {
       bool done = false;
@@ -1035,15 +1126,25 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
           }
         }
       }
-      peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u));
+      if constexpr (SPLIT)
+      {
+        if (can) // the classes of the steady paths: whatever happened here, look again
+        {
+          slow_word = false;
+          dec.classify();
+        }
+      }
+      publish();
     }
     else
     {
-      peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u));
+      publish();
       if (wave_all(bac_done))
         break;
       wave_sleep<DG_DEC_CODE_SLEEP>(); // waiting for the partner (ring full) or for stream words
     }
+    if constexpr (SPLIT)
+      continue;
     // ---- the DMA issued at the end of the previous step has landed: cook the words into the lane's own ring slots ----
     if (wave_any(requested))
     {
@@ -1077,6 +1178,79 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
       const bool low = live && !bac_done && in_loaded < k1 + 8u;
       if (wave_any(low))
         request_refill();
+    }
+  }
+  if constexpr (!SPLIT)
+    wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
+}
+
+// ---- the loading wave (workgroups of three waves per 64 channels) ---------------------------------------------------------
+// Owns the compressed stream: four words per lane come by LDS-DMA (16 bytes per lane and instruction when the slabs are
+// 16-byte aligned) into a landing area and are *cooked* into the lane's ring when they have landed -- host byte order, the
+// bits beyond the exact length cleared, zeros after the last word -- whenever the coder has left room for them; it knows
+// the word the coder has reached modulo 64 (bits 26..31 of the coder's published word).
+DG_DEV void decode_loading_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_t *pub_mine, uint32_t lane, size_t c, bool live)
+{
+  uint32_t *const iring = pair_lds + lane;
+  uint32_t *const stage_wave = pair_lds + DEC_IRING * 64;
+  const uint32_t *const pub_coder = pair_lds + (DEC_IRING + 4 + DEC_BRING) * 64 + lane;
+  const uint32_t cap_words = (uint32_t)(a.cap / 4);
+  const uint32_t *const src = reinterpret_cast<const uint32_t *>(a.in + (live ? c : 0) * a.cap);
+  StreamTail tail;
+  tail.init(live ? a.in_bits[c] : 0, cap_words);
+  const bool quads = (a.cap % 16u) == 0u && (((size_t)a.in) % 16u) == 0u;
+  uint32_t in_loaded = 0; // words staged so far: a multiple of 4
+  if (!wave_any(live))
+    return;
+  for (;;)
+  {
+    const uint32_t cp = peer_load(pub_coder);
+    const bool coder_done = !live || (cp & DEC_PUB_DONE) != 0u;
+    const uint32_t staged_ahead = (in_loaded - (cp >> 26)) & 63u; // words staged that the coder has not passed
+    const bool want = !coder_done && staged_ahead + 4u <= DEC_IRING;
+    if (wave_any(want))
+    {
+      if (want && in_loaded < tail.words)
+      {
+        if (quads)
+          dma_x4_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded), stage_wave, lane);
+        else
+        {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++)
+            if (in_loaded + j < cap_words)
+              dma_row_to_lds(reinterpret_cast<const int32_t *>(src + in_loaded + j), stage_wave + j * 64u, lane);
+        }
+      }
+      wait_vector_memory();
+      if (want)
+      {
+        uint32_t w4[4];
+        if (quads)
+        {
+          const DecodeQuad q = *reinterpret_cast<const DecodeQuad *>(stage_wave + lane * 4u);
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++)
+            w4[j] = q.w[j];
+        }
+        else
+        {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++)
+            w4[j] = stage_wave[j * 64u + lane];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+          iring[((in_loaded + j) % DEC_IRING) * 64u] = tail.cook(w4[j], in_loaded + j);
+        in_loaded += 4;
+      }
+      peer_store(pub_mine, in_loaded & 0xFFFFu);
+    }
+    else
+    {
+      if (wave_all(coder_done))
+        break;
+      wave_sleep<DG_DEC_LOAD_SLEEP>();
     }
   }
   wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
@@ -1141,6 +1315,58 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     const bool peer_done = (peer & DEC_PUB_DONE) != 0u;
     const bool got = !lane_final && avail != 0u && sp.has_room();
     const uint32_t peer_seen = peer;
+    if constexpr (!W64)
+    {
+      // The steady state: all 64 channels exist, every lane gets a whole word into a window with room for it, stands
+      // between two codewords, and the channels' ends are more than a sample ring away -- one ballot, then straight-line
+      // code for all 64 lanes: the word in, four codewords off the top (two more while some lane's window could not
+      // take its next word), and every eight rows that all lanes have, out.
+      if (full_wave && rows_stored + SRING <= T32 && wave_all(got && !(peer_done && avail == 1u) && !sp.pending() && lane_err == OK))
+      {
+        const uint32_t word = bring[(rd % DEC_BRING) * 64u];
+        peer = peer_load(pub_peer);
+        sp.push_word(word, 32u);
+        rd++;
+        peer_store(pub_mine, rd & 0xFFFFu);
+        const uint32_t t_limit = rows_stored + SRING;
+        bool more = false;
+        auto take = [&]() {
+          uint32_t sample;
+          const bool took = sp.template take_short<NARROW>(t_lane < t_limit, sample);
+          sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
+          t_lane += took ? 1u : 0u;
+          return took;
+        };
+#pragma unroll
+        for (uint32_t k = 0; k < DG_DEC_TAKES; k++)
+          more = take();
+        while (wave_any(more && !sp.has_room()))
+        {
+          more = take();
+          more = take();
+        }
+        while (wave_all(t_lane >= rows_stored + 8u))
+        {
+          const uint32_t r0 = wave_uniform(rows_stored);
+          uint32_t cand[8];
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++)
+            cand[k] = sring[((r0 + k) % SRING) * 64u];
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++)
+            store_value(r0 + k, cand[k], 0u, true);
+          rows_stored = r0 + 8u;
+        }
+        if (report != nullptr && rows_stored >= next_report)
+        {
+          if (lane == 0)
+            store_read_by_host(report, rows_stored);
+          next_report = (rows_stored / a.band_rows + 1u) * a.band_rows;
+        }
+        carry_over = true;
+        continue;
+      }
+    }
     {
       const uint32_t word = bring[(rd % DEC_BRING) * 64u];
       peer = peer_load(pub_peer);
@@ -1311,22 +1537,25 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   }
 }
 
-// One workgroup = DEC_PAIRS pairs of waves = DEC_CHANNELS channels: waves 0..3 code, wave 4 + p parses for wave p (the CU
-// deals a workgroup's waves out to its four SIMDs in turn, so the two land on the same SIMD; nothing but speed depends
-// on it).  LDS: division magics (64 KiB) | per pair: stream ring, DMA rows, decoded-word ring, two published rows,
-// sample ring -- 159 KiB for the 32-bit variants.
+// One workgroup = PAIRS groups of waves = PAIRS * 64 channels: wave p codes, wave PAIRS + p parses for it and -- SPLIT --
+// wave 2 PAIRS + p stages its stream words (the CU deals a workgroup's waves out to its four SIMDs in turn, so the waves
+// of a group land on the same SIMD; nothing but speed depends on it).  LDS: division magics (64 KiB) | per group: stream
+// ring, DMA rows, decoded-word ring, two published rows, sample ring, the loader's published row -- 160 KiB for the
+// 32-bit variants.
 // NARROW: valuesize < 32.  W64: valuesize 33..64 -- a.x is int64 [T][ld]; the parser is SegParser64 (no short-codeword
 // passes), samples take two LDS slots.  F32OUT: the decoded value, read back as valuesize bits sign extended
 // (normalize.c:36-37), leaves as (float)n / factor (:38, IEEE division) -- float32 rows [T][ld] also for W64, no
 // integer intermediate in HBM.
-// PAIRS: 4 for batches of up to 64 Ki channels, 8 (with the short sample ring) for larger ones -- two coding waves per SIMD.
-template <bool ADAPTIVE, bool NARROW = false, bool W64 = false, bool F32OUT = false, uint32_t PAIRS = DEC_PAIRS>
-__global__ void __launch_bounds__(PAIRS * 128) dega_decode_kernel(const DecodeArgs a)
+// PAIRS / SPLIT: 4 groups of three waves (one coding wave per SIMD, its two helpers beside it); or 8 pairs, with the short
+// sample ring and the coder staging its own words -- two coding waves per SIMD.
+template <bool ADAPTIVE, bool NARROW = false, bool W64 = false, bool F32OUT = false, uint32_t PAIRS = DEC_PAIRS, bool SPLIT = true>
+__global__ void __launch_bounds__(PAIRS * (SPLIT ? 192 : 128)) dega_decode_kernel(const DecodeArgs a)
 {
   constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
   // decoded samples a lane may run ahead of the slowest lane of its wave before it has to wait for the row writer
   constexpr uint32_t SRING = (W64 || PAIRS > 4) ? DEC_SRING : 64;
-  constexpr uint32_t PER_PAIR = (DEC_IRING + 4 + DEC_BRING + 2 + (W64 ? 2 : 1) * (SRING + 1)) * 64; // + a spare sample slot
+  constexpr uint32_t LOADER_ROW = DEC_IRING + 4 + DEC_BRING + 2 + (W64 ? 2 : 1) * (SRING + 1); // + a spare sample slot
+  constexpr uint32_t PER_PAIR = (LOADER_ROW + (SPLIT ? 1 : 0)) * 64;
   __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + PAIRS * PER_PAIR];
   static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
   uint32_t *const tab = lds;
@@ -1334,22 +1563,27 @@ __global__ void __launch_bounds__(PAIRS * 128) dega_decode_kernel(const DecodeAr
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = wave_uniform(threadIdx.x >> 6);
   const uint32_t pair = wave % PAIRS;
-  const bool parses = wave >= PAIRS;
+  const uint32_t role = wave / PAIRS; // 0: codes, 1: parses, 2: loads
   uint32_t *const pair_lds = lds + TAB_WORDS + pair * PER_PAIR;
-  if (!parses) // nothing handed over, nothing taken
+  uint32_t *const pub_loader = pair_lds + LOADER_ROW * 64 + lane;
+  if (role == 0) // nothing handed over, nothing taken, nothing staged
   {
     pair_lds[(DEC_IRING + 4 + DEC_BRING) * 64 + lane] = 0;
     pair_lds[(DEC_IRING + 4 + DEC_BRING + 1) * 64 + lane] = 0;
+    if (SPLIT)
+      *pub_loader = 0;
   }
   load_div_table<ADAPTIVE>(tab, a.div_magic, (uint64_t)a.T * (W64 ? 127u : 65u) + 2u); // ends with the workgroup's only barrier
 
   const size_t c_wave0 = (size_t)blockIdx.x * (PAIRS * 64u) + pair * 64u;
   const size_t c = c_wave0 + lane;
   const bool live = c < a.C;
-  if (parses)
+  if (role == 1)
     decode_parsing_wave<NARROW, W64, F32OUT, SRING>(a, pair_lds, lane, c, live, c_wave0);
+  else if (role == 0)
+    decode_coding_wave<ADAPTIVE, SPLIT>(a, tab, pair_lds, pub_loader, lane, c, live);
   else
-    decode_coding_wave<ADAPTIVE>(a, tab, pair_lds, lane, c, live);
+    decode_loading_wave(a, pair_lds, pub_loader, lane, c, live);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

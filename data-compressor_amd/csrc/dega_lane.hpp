@@ -82,6 +82,9 @@ DG_DEV uint32_t div_shift(uint32_t t)
 // Model (bac.c:39-81, binary case): index 1 = more frequent bit value (`mps`), index 2 the other, index 3 = EOF with
 // frequency 1 forever; cum[0] = tot = f1 + f2 + 1, cum[1] = c1 = f2 + 1, cum[2] = 1, cum[3] = 0.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef DG_ENC_CODE_PRIO
+#define DG_ENC_CODE_PRIO 3 // issue priority of the coding waves (0 .. 3; their helpers: 0 and 1)
+#endif
 constexpr uint32_t ENC_RAW = 16;   // raw-ring entries per lane (narrow batches); a word path needs up to 8 free
 constexpr uint32_t ENC_ORING = 32; // staged output words per lane on the writer's side (drained in groups of 16)
 
@@ -165,8 +168,14 @@ struct BacCoder
   // this one, so the wait ends.  (Only lanes of such a path are active here; the others wait at the reconvergence.)
   DG_DEV void dump_when_room()
   {
-    while (!raw_room(rwr, peer_load(peer), 1u))
-      wave_sleep<1>();
+    if (!raw_room(rwr, peer_load(peer), 1u))
+    {
+      wave_priority<0>(); // the writer needs the issue slots this wave would poll away
+      do
+        wave_sleep<2>();
+      while (!raw_room(rwr, peer_load(peer), 1u));
+      wave_priority<DG_ENC_CODE_PRIO>();
+    }
     dump();
   }
 
@@ -883,6 +892,8 @@ struct StreamTail
 // x1 = range*cum[1]/cum[0] and x2 = range*cum[2]/cum[0] -- the very quantities the interval update needs anyway
 // (integer identity: v - s >= floor(R*c/t)  <=>  (v - s + 1) * t > R * c).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t DCLS_FAST = 0, DCLS_SPLIT = 1, DCLS_GENERAL = 2; // cheapest first, as the encoder's CLS_*
+
 template <bool ADAPTIVE>
 struct BacDecoder
 {
@@ -893,9 +904,12 @@ struct BacDecoder
   // around a halving of the counts -- first 0 .. h, then, a step later, h+1 .. 31; part_bits keeps the first part's bits.
   uint32_t part_lo, part_hi, part_bits;
   bool part_halves; // the first part ends at a halving of the counts (else: at a change of the division shift, or nowhere)
+  uint32_t cls, safe; // the class of the next word (DCLS_*) and for how many words it still holds (see classify)
 
   DG_DEV void init()
   {
+    cls = DCLS_GENERAL;
+    safe = 0;
     part_halves = false;
     A = 0;
     B = 0;
@@ -1016,6 +1030,38 @@ struct BacDecoder
   DG_DEV bool split_ok() const
   {
     return ADAPTIVE && (part_lo != 0u || halving_ahead() || shift_change_ahead());
+  }
+
+  // The class of the next word and for how many words it holds, as BacCoder::classify (no dump capacity to mind here):
+  // evaluated when `safe` has run out, so that the steady state of the kernel is one decrement per word.
+  DG_DEV void classify()
+  {
+    if (!ADAPTIVE)
+    {
+      cls = DCLS_FAST;
+      safe = 0x40000000u;
+      return;
+    }
+    safe = 0;
+    if (part_lo != 0u)
+    {
+      cls = DCLS_SPLIT; // the second part of a word
+      return;
+    }
+    const uint32_t diff = tot + 1u - 2u * c1; // f1 - f2
+    const uint32_t w_halve = (MAX_FREQUENCY - tot) >> 5;
+    const uint32_t w_swap = diff >> 5;
+    const uint32_t pw = 0x80000000u >> (clz32(tot - 1u) - 1u); // the power of two above tot - 1
+    const uint32_t w_shift = pw >= tot + 31u ? (pw - tot + 1u) >> 5 : 0u;
+    uint32_t w = w_halve < w_swap ? w_halve : w_swap;
+    w = w < w_shift ? w : w_shift;
+    if (w != 0u)
+    {
+      cls = DCLS_FAST;
+      safe = w;
+    }
+    else
+      cls = (halving_ahead() || shift_change_ahead()) ? DCLS_SPLIT : DCLS_GENERAL;
   }
 
   DG_DEV void begin_word() // before a masked word path: which symbols it decodes

@@ -314,28 +314,16 @@ extern "C" __attribute__((visibility("default"))) int sim_lzmh_decode(const uint
   return 0;
 }
 
-// the 8-wave workgroup shape that the library uses for batches of more than 64 Ki channels, forced on a small batch
-extern "C" __attribute__((visibility("default"))) int sim_encode_wide(const int32_t *x, size_t C, size_t T, size_t ld, int adaptive, uint8_t *out, size_t cap, uint64_t *bits, int32_t *err)
-{
-  static const std::vector<uint32_t> tab = make_table();
-  EncodeArgs a{x, C, T, ld, out, cap, bits, err, tab.data(), 32u};
-  const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 4 rows per batch, 16 / 8 / 16 ring slots
-  if (adaptive)
-    sim::launch(dega_encode_kernel<true, false, 4, 16, 8, 16, false, false, 8, false>, grid, dim3(1024), a);
-  else
-    sim::launch(dega_encode_kernel<false, false, 4, 16, 8, 16, false, false, 8, false>, grid, dim3(1024), a);
-  return 0;
-}
-
+// the 8-pair workgroup shape that the library uses for decoding batches of more than 64 Ki channels, forced on a small batch
 extern "C" __attribute__((visibility("default"))) int sim_decode_wide(const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld, int adaptive, int32_t *x, int32_t *err)
 {
   static const std::vector<uint32_t> tab = make_table();
   DecodeArgs a{in, cap, in_bits, C, T, ld, x, err, tab.data(), nullptr, 32u};
   const dim3 grid((unsigned)((C + 511) / 512)); // 8 pairs of waves, 16-sample ring
   if (adaptive)
-    sim::launch(dega_decode_kernel<true, false, false, false, 8>, grid, dim3(1024), a);
+    sim::launch(dega_decode_kernel<true, false, false, false, 8, false>, grid, dim3(1024), a);
   else
-    sim::launch(dega_decode_kernel<false, false, false, false, 8>, grid, dim3(1024), a);
+    sim::launch(dega_decode_kernel<false, false, false, false, 8, false>, grid, dim3(1024), a);
   return 0;
 }
 

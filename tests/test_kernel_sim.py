@@ -119,11 +119,9 @@ def test_decode_kernel_logic_on_golden_sets(sim):
 
 
 def test_wide_workgroup_shape_on_golden_sets(sim):
-    """The wide workgroups (8 pairs of waves, 4-row fills, 16/24-word rings) the library uses for batches of more than 64 Ki channels,
-    forced on the small golden batches: same streams, same samples back."""
-    sig_e = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    """The wide workgroups (8 pairs of waves, 16-sample ring) the library uses for decoding batches of more than 64 Ki channels,
+    forced on the small golden batches: the same samples back.  (The encoder has one workgroup shape.)"""
     sig_d = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-    sim.sim_encode_wide.argtypes = sig_e
     sim.sim_decode_wide.argtypes = sig_d
     z = np.load(os.path.join(GOLDEN, "channels.npz"))
     for name in ("walk300_T96", "wild", "with_errors", "ragged_small"):
@@ -134,7 +132,7 @@ def test_wide_workgroup_shape_on_golden_sets(sim):
             out = np.zeros((Cn, cap), dtype=np.uint8)
             bits = np.zeros(Cn, dtype=np.uint64)
             err = np.zeros(Cn, dtype=np.int32)
-            sim.sim_encode_wide(x.ctypes.data, Cn, T, Cn, ad, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
+            sim.sim_encode(x.ctypes.data, Cn, T, Cn, ad, out.ctypes.data, cap, bits.ctypes.data, err.ctypes.data)
             gs, gb, ge = z["%s.%s.stream" % (name, tag)], z["%s.%s.bits" % (name, tag)], z["%s.%s.err" % (name, tag)]
             assert (err == ge).all(), name
             ok = ge == 0
