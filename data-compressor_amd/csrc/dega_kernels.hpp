@@ -153,13 +153,19 @@ DG_DEV void load_div_table(uint32_t *tab, const uint32_t *gtab, uint64_t symbols
 #define DG_ENC_CODE_PRIO 3
 #endif
 #ifndef DG_DEC_PARSE_SLEEP
-#define DG_DEC_PARSE_SLEEP 2
+#define DG_DEC_PARSE_SLEEP 6
 #endif
 #ifndef DG_DEC_CODE_SLEEP
 #define DG_DEC_CODE_SLEEP 1
 #endif
 #ifndef DG_DEC_LOAD_SLEEP
 #define DG_DEC_LOAD_SLEEP 8
+#endif
+#ifndef DG_DEC_PARSE_PRIO
+#define DG_DEC_PARSE_PRIO 0
+#endif
+#ifndef DG_DEC_LOAD_PRIO
+#define DG_DEC_LOAD_PRIO 0
 #endif
 #ifndef DG_DEC_CODE_PRIO
 #define DG_DEC_CODE_PRIO 0
@@ -948,6 +954,13 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
     peer_store(pub_mine, (wr & 0xFFFFu) | pub_flags | (bac_done ? DEC_PUB_DONE : 0u) | (SPLIT ? ((uint32_t)(dec.bp >> 5) & 63u) << 26 : 0u));
   };
   dec.classify();
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 128) && !defined(DEGA_SIM)
+  // diagnostic build: what the coding wave's passes were (steady / steady masked / general / nothing to do), in cycles too
+  uint64_t dd_n[4] = {0, 0, 0, 0}, dd_c[4] = {0, 0, 0, 0}, dd_t = __builtin_amdgcn_s_memtime();
+#define DD_COUNT(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); dd_n[k]++; dd_c[k] += now_ - dd_t; dd_t = now_; } while (0)
+#else
+#define DD_COUNT(k)
+#endif
 
   for (;;)
   {
@@ -1021,6 +1034,7 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
             dec.classify();
         }
         publish();
+        DD_COUNT(plain ? 0 : 1);
         continue;
       }
     }
@@ -1135,6 +1149,7 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
         }
       }
       publish();
+      DD_COUNT(2);
     }
     else
     {
@@ -1142,6 +1157,7 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
       if (wave_all(bac_done))
         break;
       wave_sleep<DG_DEC_CODE_SLEEP>(); // waiting for the partner (ring full) or for stream words
+      DD_COUNT(3);
     }
     if constexpr (SPLIT)
       continue;
@@ -1182,6 +1198,10 @@ DG_DEV void decode_coding_wave(const DecodeArgs &a, const uint32_t *tab, uint32_
   }
   if constexpr (!SPLIT)
     wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 128) && !defined(DEGA_SIM)
+  if (live && lane < 8) // (the stream lengths have been read long ago)
+    const_cast<uint64_t *>(a.in_bits)[c] = lane < 4 ? dd_n[lane] : dd_c[lane - 4];
+#endif
 }
 
 // ---- the loading wave (workgroups of three waves per 64 channels) ---------------------------------------------------------
@@ -1202,6 +1222,7 @@ DG_DEV void decode_loading_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   uint32_t in_loaded = 0; // words staged so far: a multiple of 4
   if (!wave_any(live))
     return;
+  wave_priority<DG_DEC_LOAD_PRIO>();
   for (;;)
   {
     const uint32_t cp = peer_load(pub_coder);
@@ -1276,10 +1297,20 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
   const uint32_t T32 = (uint32_t)a.T;
   int32_t lane_err = OK;
   bool carry_over = true;   // the previous pass changed something a further pass could build on
+  bool force_general = false; // (wave uniform) a lane's window holds something the steady pass cannot take
   const bool full_wave = c_wave0 + 64u <= a.C;
   if (!wave_any(live))
     return; // a wave past the last channel
   uint32_t peer = peer_load(pub_peer);
+  wave_priority<DG_DEC_PARSE_PRIO>();
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 128) && !defined(DEGA_SIM)
+  // diagnostic build: the parsing wave's passes (steady / general / cheap polls / sleeps in the general pass), in cycles too
+  uint32_t dp_n[4] = {0, 0, 0, 0};
+  uint64_t dp_c[4] = {0, 0, 0, 0}, dp_t = __builtin_amdgcn_s_memtime();
+#define DP_COUNT(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); dp_n[k]++; dp_c[k] += now_ - dp_t; dp_t = now_; } while (0)
+#else
+#define DP_COUNT(k)
+#endif
   uint32_t *const report = a.rows_done != nullptr ? a.rows_done + c_wave0 / 64u : nullptr; // (wave uniform)
   uint32_t next_report = a.band_rows;
 
@@ -1317,16 +1348,17 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     const uint32_t peer_seen = peer;
     if constexpr (!W64)
     {
-      // The steady state: all 64 channels exist, every lane gets a whole word into a window with room for it, stands
-      // between two codewords, and the channels' ends are more than a sample ring away -- one ballot, then straight-line
-      // code for all 64 lanes: the word in, four codewords off the top (two more while some lane's window could not
-      // take its next word), and every eight rows that all lanes have, out.
-      if (full_wave && rows_stored + SRING <= T32 && wave_all(got && !(peer_done && avail == 1u) && !sp.pending() && lane_err == OK))
+      // The steady state: all 64 channels exist, no lane is at its stream's end, inside a long codeword or in error, and
+      // the channels' ends are more than a sample ring away -- two ballots, then straight-line code for all 64 lanes: the
+      // word in (for the lanes that have one and room for it), four codewords off the top (two more while some lane's
+      // window could not take its next word), and every eight rows that all lanes have, out.  A lane whose window holds
+      // 32 bits and no short codeword (a long one: first samples, jumps) sends the next pass through the general code.
+      if (full_wave && !force_general && rows_stored + SRING <= T32 && wave_all(!lane_final && !peer_done && !sp.pending() && lane_err == OK) && wave_any(got))
       {
         const uint32_t word = bring[(rd % DEC_BRING) * 64u];
         peer = peer_load(pub_peer);
-        sp.push_word(word, 32u);
-        rd++;
+        sp.push_word(got ? word : 0u, got ? 32u : 0u);
+        rd += got ? 1u : 0u;
         peer_store(pub_mine, rd & 0xFFFFu);
         const uint32_t t_limit = rows_stored + SRING;
         bool more = false;
@@ -1345,6 +1377,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
           more = take();
           more = take();
         }
+        force_general = wave_any(!more && t_lane < t_limit && sp.cnt >= 32u);
         while (wave_all(t_lane >= rows_stored + 8u))
         {
           const uint32_t r0 = wave_uniform(rows_stored);
@@ -1363,7 +1396,17 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
             store_read_by_host(report, rows_stored);
           next_report = (rows_stored / a.band_rows + 1u) * a.band_rows;
         }
-        carry_over = true;
+        carry_over = force_general; // (else what is left in the windows waits for the next word: nothing to gain from a pass without one)
+        DP_COUNT(0);
+        continue;
+      }
+      force_general = false;
+      // nothing new and nothing pending: a cheap poll (the general pass below costs a few hundred instructions)
+      if (!carry_over && !wave_any((avail != 0u && !lane_final) || (live && peer_done && !lane_final)))
+      {
+        peer = peer_load(pub_peer);
+        wave_sleep<DG_DEC_PARSE_SLEEP>();
+        DP_COUNT(2);
         continue;
       }
     }
@@ -1380,6 +1423,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     if (!wave_any(got || (final_in && !lane_final)) && !carry_over)
     {
       wave_sleep<DG_DEC_PARSE_SLEEP>();
+      DP_COUNT(3);
       continue;
     }
     if (final_in && (peer_seen & DEC_PUB_BAD) != 0u && lane_err == OK)
@@ -1525,6 +1569,7 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     if (wave_all(lane_final) && (rows_stored >= T32 || (a.out_count != nullptr && !wave_any(t_lane > rows_stored))))
       break;
     carry_over = rows_stored != rows_before || wave_any(t_lane != t_before || lane_final != final_before);
+    DP_COUNT(1);
   }
   peer_store(pub_mine, (rd & 0xFFFFu) | DEC_PUB_FINAL);
   if (report != nullptr && lane == 0)
@@ -1534,6 +1579,10 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
     a.err[c] = lane_err;
     if (a.out_count != nullptr)
       a.out_count[c] = t_lane;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 128) && !defined(DEGA_SIM)
+    if (lane < 8)
+      a.err[c] = lane < 4 ? (int32_t)dp_n[lane] : (int32_t)(dp_c[lane - 4] >> 10); // (cycles in units of 1024)
+#endif
   }
 }
 

@@ -35,7 +35,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         torch.cuda.synchronize()
         n, ms = ctx.profile_read(1)
         r2 = {"lib": os.path.basename(dca.LIB_PATH), "decode_kernel_ms": round(ms, 4)}
-        if "diag32" not in dca.LIB_PATH:  # (the decode kernel carries no stamps)
+        if "diag128" in dca.LIB_PATH:  # the decode kernel's pass counters: the coder's over in_bits, the parser's over err
+            bb = b2.cpu().numpy().reshape(-1, 64)
+            ee = derr.cpu().numpy().reshape(-1, 64)
+            cn = ["steady", "steady_masked", "general", "idle"]
+            pn = ["steady", "general", "cheap_polls", "sleeps_in_general"]
+            r2["coder_passes_per_wave"] = {cn[k]: {"count": int(bb[:, k].mean()), "cycles": int(bb[:, 4 + k].mean())} for k in range(4)}
+            r2["parser_passes_per_wave"] = {pn[k]: {"count": int(ee[:, k].mean()), "cycles": int(ee[:, 4 + k].mean()) * 1024} for k in range(4)}
+        if "diag" not in dca.LIB_PATH:
             r2["round_trip_ok"] = bool((y == x).all())
         print(json.dumps(r2))
 else:
