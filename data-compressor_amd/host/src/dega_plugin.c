@@ -19,7 +19,8 @@
  * devices in DEGA_DEVICES, else all), which splits the channels into one range per device and concatenates the packed
  * streams on the host.  Without a GPU the codecs fail with ERROR_LIBRARY_INIT -- there is no CPU path here.
  *
- * num_channels=n (this project's mirror only; the reference has no batch notion):
+ * num_channels=n (this project's mirror, and a reference tree with the edit of INTEGRATION.md 2b; the reference as shipped
+ * has no batch notion):
  *   dega / fdega: the input is n interleaved channels, sample-major -- i.e. the [T][C] layout the kernels want -- and the
  *                 output is a small container (all integers big-endian):
  *                   "DEGB" | u32 version = 1 | u64 C | u64 T | C x u64 bit lengths | the C streams, each padded to a whole byte
@@ -57,11 +58,12 @@ static io_int_t get_group(FILE *log, dega_hip_group **group)
 
 static size_t channels_of(const options_t *options)
 {
-#ifdef DC_AMD_ENC_DEC_H
+#if defined(DC_AMD_ENC_DEC_H) || defined(DC_OPTIONS_HAVE_NUM_CHANNELS)
+  /* this project's mirror header, or the reference's enc_dec.h with the num_channels edit of INTEGRATION.md 2b */
   return options->num_channels > 0 ? options->num_channels : 1;
 #else
   (void)options;
-  return 1; /* the reference's options_t has no batch dimension */
+  return 1; /* the reference's options_t as shipped has no batch dimension */
 #endif
 }
 

@@ -323,3 +323,67 @@ def test_reference_dccli_runs_its_make_test_chain_through_the_plugin(input_txt, 
     assert p.returncode == 0 and out.read_bytes() == input_txt.read_bytes()
     # an option the row does not list is refused by the reference's own parser
     assert ref_cli([str(input_txt), str(enc), "decode", "csv", "#", "encode", "dega", "normalization_factor=3"]).returncode != 0
+
+
+@pytest.mark.gpu
+def test_reference_dccli_codes_a_batch_of_channels(tmp_path):
+    """The batch dimension through the reference's OWN DCCLI: built from the reference's sources with the num_channels
+    edit of INTEGRATION.md 2b (`size_t num_channels` appended to options_t, OPTION_NUM_CHANNELS, its sorted
+    option_descriptions[] row and default -- applied to scratch copies by oracle/Makefile), its option parser accepts
+    `num_channels=4096`, its stage loop (DCCLI/src/cli.c:447) hands the plugin 4 096 interleaved channels, and every
+    inner stream of the container it writes is the oracle's for that channel; `decode dega ... num_channels=4096` returns
+    the input.  The same for `glzmh` (pieces of a text), decoded piece by piece by the oracle."""
+    if not os.path.exists(REF_CLI_GPU):
+        pytest.skip("oracle/_ref/DCCLI_gpu is built in the container that holds /root/reference (make -C oracle)")
+    rng = np.random.default_rng(17)
+    T, Cn = 200, 4096
+    x = (np.cumsum(rng.integers(-60, 61, (T, Cn)), axis=0) + 30000).astype(">i4")
+    src, enc, dec = tmp_path / "batch.be32", tmp_path / "batch.degb", tmp_path / "batch.out"
+    src.write_bytes(x.tobytes())  # sample-major interleaving = [T][C]
+    p = ref_cli([str(src), str(enc), "encode", "dega", "adaptive", "num_channels=%d" % Cn])
+    assert p.returncode == 0, p.stdout + p.stderr
+    blob = enc.read_bytes()
+    assert blob[:4] == b"DEGB" and int.from_bytes(blob[8:16], "big") == Cn and int.from_bytes(blob[16:24], "big") == T
+    lens = [int.from_bytes(blob[24 + 8 * c: 32 + 8 * c], "big") for c in range(Cn)]
+    off = 24 + 8 * Cn
+    want_out, want_bits, want_err = orc.encode_batch_tc(x.astype(np.int32), 1, cap=(orc.lib().orc_dega_worst_case_bytes(T) + 3) & ~3)
+    assert (want_err == 0).all()
+    for c in range(Cn):
+        nb = (lens[c] + 7) // 8
+        assert lens[c] == int(want_bits[c]) and blob[off: off + nb] == want_out[c, :nb].tobytes(), c
+        off += nb
+    assert off == len(blob)
+    p = ref_cli([str(enc), str(dec), "decode", "dega", "adaptive", "num_channels=%d" % Cn])
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert dec.read_bytes() == x.tobytes()
+    # chained inside one invocation: the exact bit length goes from stage to stage in memory
+    p = ref_cli([str(src), str(dec), "encode", "dega", "adaptive", "num_channels=%d" % Cn, "#", "decode", "dega", "adaptive", "num_channels=%d" % Cn])
+    assert p.returncode == 0 and dec.read_bytes() == x.tobytes()
+    # the float entry: csv text of 8 interleaved channels -> fdega -> back (the reference's csv codec on both ends)
+    vals = (np.cumsum(rng.integers(-40, 41, (300, 8)), axis=0) + 20000) / 100.0
+    txt = tmp_path / "in.txt"
+    txt.write_text("".join("%.2f\n" % v for v in vals.reshape(-1)))
+    p = ref_cli([str(txt), str(dec), "decode", "csv", "#", "encode", "fdega", "adaptive", "num_channels=8", "#", "decode", "fdega", "adaptive", "num_channels=8",
+                 "#", "encode", "csv"])
+    assert p.returncode == 0 and dec.read_bytes() == txt.read_bytes()
+    # glzmh: the text cut into 64 pieces, each the stream `encode lzmh` writes for that piece
+    text = "".join("%d.%02d\n" % (v // 100, v % 100) for v in x[:, :40].astype(np.int64).reshape(-1).tolist()).encode()
+    tsrc, tenc = tmp_path / "t.txt", tmp_path / "t.lzmb"
+    tsrc.write_bytes(text)
+    p = ref_cli([str(tsrc), str(tenc), "encode", "glzmh", "num_channels=64"])
+    assert p.returncode == 0, p.stdout + p.stderr
+    blob = tenc.read_bytes()
+    assert blob[:4] == b"LZMB" and int.from_bytes(blob[8:16], "big") == 64
+    piece = (len(text) + 63) // 64
+    off = 16 + 16 * 64
+    for c in range(64):
+        nbytes, nbits = int.from_bytes(blob[16 + 16 * c: 24 + 16 * c], "big"), int.from_bytes(blob[24 + 16 * c: 32 + 16 * c], "big")
+        part = text[c * piece: (c + 1) * piece]
+        assert nbytes == len(part)
+        r, b, n = orc.stage("lzmh", True, part, 8 * len(part))
+        assert r == 0 and n == nbits and blob[off: off + (n + 7) // 8] == b[: (n + 7) // 8], c
+        off += (nbits + 7) // 8
+    p = ref_cli([str(tenc), str(dec), "decode", "glzmh", "num_channels=64"])
+    assert p.returncode == 0 and dec.read_bytes() == text
+    # the reference's parser knows the option now -- and still refuses it on a row that does not list it
+    assert ref_cli([str(src), str(enc), "encode", "diff", "num_channels=4"]).returncode != 0
