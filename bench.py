@@ -242,6 +242,63 @@ def end_to_end(env, args, x, bits_dev):
     return res
 
 
+def group_end_to_end(env, args, xh):
+    """The product's multi-GPU path: dega_hip_group_encode / _decode called from ONE process over all
+    --gpus N devices -- contiguous channel ranges per device, a host thread and a pipeline each, host-side concatenate, no
+    collective -- on N x (one device's share) host samples, pinned and pageable, with the single-device figure beside it.
+    At N = 1 also the group [0, 0] against [0]: what the threads and the concatenate cost.  Never the headline value."""
+    import numpy as np
+    dca = env.dca
+    T, n = xh.shape
+    world = env.world
+    res = {"unit": "Msamples/s", "what": "dega_hip_group_encode/_decode from one process: channel ranges per device, host-side concatenate, no collective",
+           "channels_per_device": n, "samples_per_channel": T}
+
+    def measure(devices, xs):
+        out = {}
+        Tn, Cn = xs.shape
+        g = dca.Group(devices)
+        try:
+            pinned = dca.PinnedArray((Tn, Cn), np.int32)
+            pinned.array[:] = xs
+            packed_pin = dca.PinnedArray((Cn * (Tn * 2 + 64),), np.uint8)
+            page_buf = np.zeros(Cn * (Tn * 2 + 64), dtype=np.uint8)
+            for name, src, dst in (("pageable", xs, page_buf), ("pinned", pinned.array, packed_pin.array)):
+                g.encode_job(src, adaptive=1, packed=dst)  # grows the contexts' buffers
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    pk, off, b, e = g.encode_job(src, adaptive=1, packed=dst)
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                out["encode_%s_value" % name] = round(Cn * Tn / best / 1e6, 2)
+                out["encode_%s_seconds" % name] = round(best, 4)
+            back, derr = g.decode_job(pk, off, b, Tn, adaptive=1, out=pinned.array)
+            t0 = time.perf_counter()
+            back, derr = g.decode_job(pk, off, b, Tn, adaptive=1, out=pinned.array)
+            dt = time.perf_counter() - t0
+            out["decode_pinned_value"] = round(Cn * Tn / dt / 1e6, 2)
+            out["round_trip_ok"] = bool((derr == 0).all() and (e == 0).all() and (back == xs).all())
+            out["bits"] = b.astype(np.int64)
+            pinned.free()
+            packed_pin.free()
+        finally:
+            g.close()
+        return out
+
+    one = measure([0], xh)
+    bits_one = one.pop("bits")
+    res["devices_1"] = one
+    if world == 1:
+        two = measure([0, 0], xh)  # two members on the one device: the partition, the threads and the concatenate are the same code
+        res["members_2_on_one_device"] = dict(two, streams_equal_single=bool((two.pop("bits") == bits_one).all()))
+    else:
+        xs = np.ascontiguousarray(np.tile(xh, (1, world)))
+        many = measure(list(range(world)), xs)
+        res["devices_%d" % world] = dict(many, streams_equal_single=bool((many.pop("bits").reshape(world, -1) == bits_one[None, :]).all()))
+    return res
+
+
 def run_dega(env, args):
     import numpy as np
     torch, ctx = env.torch, env.ctx
@@ -344,6 +401,10 @@ def run_dega(env, args):
                 res["cpu_all_cores"] = cpu_all_cores(env.pool, env.ncores, xs)
         if world == 1 and args.end_to_end_channels > 0:
             res["end_to_end"] = end_to_end(env, args, x, bits)
+        if args.end_to_end_channels > 0:
+            import numpy as np
+            n = min(args.end_to_end_channels, C_)
+            res.setdefault("end_to_end", {})["group"] = group_end_to_end(env, args, np.ascontiguousarray(x[:, :n].cpu().numpy()))
     del x, out, bits, err
     torch.cuda.empty_cache()
     return res
@@ -442,6 +503,46 @@ def lzmh_cpu_baseline(texts, gpu_out, gpu_bits):
             "gpu_streams_bit_exact": mismatches == 0}
 
 
+def lzmh_end_to_end(env, text, lens, bits_dev, n):
+    """The host-pointer path of the second codec (dega_hip_group_lzmh_encode / _decode: chunks of channels on their own
+    streams, upload + kernel + pack + download overlapped; packed streams out): host text in, packed streams out, and back.
+    A channel's serial chain takes the same kernel time however few channels there are, so this is the kernel's time plus
+    what the copies of the first and last chunk add.  Never the headline value."""
+    import numpy as np
+    dca = env.dca
+    th = np.ascontiguousarray(text[:n].cpu().numpy())
+    lh = lens[:n].cpu().numpy().astype(np.uint64)
+    nbytes = int(lh.sum())
+    res = {"unit": "MB/s", "channels": n, "text_bytes": nbytes,
+           "what": "dega_hip_group_lzmh_encode/_decode on one device: host text in, packed streams out (and back), pipeline over chunks of channels"}
+    g = dca.Group([0])
+    try:
+        pinned = dca.PinnedArray(th.shape, np.uint8)
+        pinned.array[:] = th
+        packed_pin = dca.PinnedArray((nbytes + nbytes // 4 + 64 * n + 64,), np.uint8)
+        page_buf = np.zeros(nbytes + nbytes // 4 + 64 * n + 64, dtype=np.uint8)
+        for name, src, dst in (("pageable", th, page_buf), ("pinned", pinned.array, packed_pin.array)):
+            g.lzmh_encode_job(src, lh, packed=dst)
+            t0 = time.perf_counter()
+            pk, off, b, e = g.lzmh_encode_job(src, lh, packed=dst)
+            dt = time.perf_counter() - t0
+            res["encode_%s_value" % name] = round(nbytes / dt / 1e6, 1)
+            res["encode_%s_seconds" % name] = round(dt, 4)
+        res["streams_equal_device_resident"] = bool((b.astype(np.int64) == bits_dev[:n].cpu().numpy()).all() and (e == 0).all())
+        back, blens, berr = g.lzmh_decode_job(pk, off, b, th.shape[1], out=pinned.array)
+        t0 = time.perf_counter()
+        back, blens, berr = g.lzmh_decode_job(pk, off, b, th.shape[1], out=pinned.array)
+        dt = time.perf_counter() - t0
+        res["decode_pinned_value"] = round(nbytes / dt / 1e6, 1)
+        idx = np.arange(th.shape[1])[None, :] < lh[:, None].astype(np.int64)
+        res["decode_round_trip_ok"] = bool((berr == 0).all() and (blens == lh).all() and ((back == th) | ~idx).all())
+        pinned.free()
+        packed_pin.free()
+    finally:
+        g.close()
+    return res
+
+
 def run_lzmh(env, args):
     """BASELINE configs[3]: LZMH encode of the cfg2 channels rendered as ASCII "%d.%02d\\n" lines, one GPU
     lane per channel.  Same contract as the DEGA line; the unit is bytes of text."""
@@ -530,6 +631,8 @@ def run_lzmh(env, args):
         }
         if round_trip is not None:
             res["round_trip"] = round_trip
+        if world == 1 and getattr(args, "lzmh_end_to_end_channels", 0) > 0:
+            res["end_to_end"] = lzmh_end_to_end(env, text, lens, bits, min(args.lzmh_end_to_end_channels, C_))
         if world == 1 and args.cpu_channels > 0:
             # a bounded sample: the reference codes ~7 MB/s, so 128 channels of 600 kB are ~10 s of CPU work
             n = min(max(1, args.cpu_channels // 2), C_)
@@ -554,8 +657,15 @@ def extras(env, args):
     # configs[3]: LZMH of the cfg2 channels as ASCII lines, 39.4 GB of text, with the reference's `encode lzmh` beside it
     a = argparse.Namespace(**vars(args))
     a.channels, a.samples, a.step_size, a.steps, a.warmup, a.cpu_channels, a.lzmh_input, a.no_round_trip = 65536, 86400, 50, 2, 1, 128, "ascii", False
+    a.lzmh_end_to_end_channels = 4096
     r = run_lzmh(env, a)
-    out["cfg4_lzmh"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip", "cpu_baseline", "gpu_over_cpu") if k in r}
+    out["cfg4_lzmh"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip", "cpu_baseline", "gpu_over_cpu", "end_to_end") if k in r}
+    # the same channels as the raw big-endian int32 bytes `encode normalize` hands on ("also report")
+    a = argparse.Namespace(**vars(args))
+    a.channels, a.samples, a.step_size, a.steps, a.warmup, a.cpu_channels, a.lzmh_input, a.no_round_trip = 65536, 86400, 50, 1, 1, 0, "raw", False
+    a.lzmh_end_to_end_channels = 0
+    r = run_lzmh(env, a)
+    out["cfg4_lzmh_raw_int32"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "round_trip") if k in r}
     # configs[4]: one GPU's share (1 Mi channels x 86 400), streamed in batches, encode + decode + compare on the device
     a = argparse.Namespace(**vars(args))
     a.channels, a.samples, a.step_size, a.steps, a.warmup, a.batch_channels = 1048576, 86400, 50, 1, 0, 131072
@@ -584,6 +694,7 @@ def main():
     ap.add_argument("--workload", choices=("dega", "lzmh", "roundtrip"), default="dega",
                     help="dega = BASELINE configs[1] (the headline metric); lzmh = configs[3], the same channels as ASCII lines through LZMH; "
                          "roundtrip = one GPU's share of configs[4]: --channels streamed in batches of --batch-channels, encode + decode + compare")
+    ap.add_argument("--lzmh-end-to-end-channels", type=int, default=0, help="lzmh workload: channels of the host-pointer (PCIe-inclusive) measurement (0 = skip)")
     ap.add_argument("--batch-channels", type=int, default=131072, help="roundtrip workload: channels per batch (x + slabs + decoded samples must fit HBM)")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "dega_hip_group_last_error": (C.c_char_p, [_P]),
     "dega_hip_group_encode": (C.c_int, [_P, _P, _P, _P, _Z, _P, _P, _P]),
     "dega_hip_group_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "dega_hip_group_lzmh_encode": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P]),
+    "dega_hip_group_lzmh_decode": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, _P]),
     "dega_hip_pinned_alloc": (_P, [_Z]),
     "dega_hip_pinned_free": (None, [_P]),
     "dega_hip_profile": (C.c_int, [_P, C.c_int]),
@@ -242,6 +244,38 @@ class Group(_JobCalls):
     def _check(self, ret, what):
         if ret != OK:
             raise DegaError(ret, "%s [%s]" % (what, library().dega_hip_group_last_error(self._h).decode()))
+
+    def lzmh_encode_job(self, text, lens, packed=None):
+        """text: uint8 [C, stride] host array (stride a multiple of 16; numpy or a PinnedArray's .array), lens: bytes per
+        channel.  Returns (packed uint8, offsets uint64 [C + 1], bits uint64 [C], err int32 [C]); channel c's stream is
+        packed[offsets[c]:offsets[c + 1]].  The host pipeline on every device of the group (dega_hip_group_lzmh_encode)."""
+        import numpy as np
+        Cn, stride = text.shape
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        if packed is None:
+            packed = np.empty(int(lens.sum()) * 5 // 4 + 64 * Cn + 64, dtype=np.uint8)
+        offsets = np.zeros(Cn + 1, dtype=np.uint64)
+        bits = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_group_lzmh_encode(self._h, text.ctypes.data, stride, lens.ctypes.data, Cn, packed.ctypes.data, packed.size,
+                                                   offsets.ctypes.data, bits.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_group_lzmh_encode")
+        return packed, offsets, bits, err
+
+    def lzmh_decode_job(self, packed, offsets, bits, stride, out=None):
+        """The inverse: (text uint8 [C, stride], lens uint64 [C], err int32 [C])."""
+        import numpy as np
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        Cn = bits.size
+        if out is None:
+            out = np.zeros((Cn, stride), dtype=np.uint8)
+        lens = np.zeros(Cn, dtype=np.uint64)
+        err = np.zeros(Cn, dtype=np.int32)
+        ret = library().dega_hip_group_lzmh_decode(self._h, packed.ctypes.data, offsets.ctypes.data, bits.ctypes.data, Cn, out.ctypes.data, stride,
+                                                   lens.ctypes.data, err.ctypes.data)
+        self._check(ret, "dega_hip_group_lzmh_decode")
+        return out, lens, err
 
 
 class Context(_JobCalls):

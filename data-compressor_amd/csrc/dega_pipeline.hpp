@@ -1555,3 +1555,302 @@ extern "C" int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, s
   HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
   return DEGA_OK;
 }
+
+// ---- LZMH through the pipeline: chunks of channels on their own streams, packed streams out / in, and the group -----------
+// A channel's text is a row of `stride` bytes ([C][stride], in_len[c] of them meaningful), so a range of channels is one
+// contiguous block: upload -> encode kernel -> offsets -> gather -> download of the packed stream bytes per chunk, the
+// chunks overlapping on their streams exactly as the DEGA path's do.  Channels are independent (every stream starts from
+// an empty history: lzmh.c:139-143,396), so a group gives every device a contiguous range and the host concatenates.
+
+static ChunkPlan lzmh_plan(size_t C, size_t stride, size_t cap)
+{
+  ChunkPlan p = plan_chunks(C, stride, 2 * stride + 2 * cap + 64, 0);
+  // (whole 256-channel workgroups per chunk where the batch allows: plan_chunks rounds to 512)
+  return p;
+}
+
+static int lzmh_encode_share(dega_hip_ctx *ctx, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *packed, size_t packed_cap,
+                             uint64_t *offsets, uint64_t *out_bits, int32_t *err, uint64_t *total_out)
+{
+  int ret;
+  Pipeline *pl;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = pipeline_get(ctx, &pl)) != DEGA_OK)
+    return ret;
+  const size_t cap = dega_hip_lzmh_worst_case_bytes(stride);
+  const ChunkPlan plan = lzmh_plan(C, stride, cap);
+  const bool in_pinned = is_pinned(in), out_pinned = is_pinned(packed);
+  struct Ch
+  {
+    size_t c0, n;
+    int slot;
+  };
+  std::vector<Ch> chunks(plan.nchunks);
+  uint64_t running = 0;
+  bool out_full = false;
+  auto stage1 = [&](size_t k) -> int {
+    Ch &ch = chunks[k];
+    ch.c0 = k * plan.chunk_channels;
+    ch.n = std::min(plan.chunk_channels, C - ch.c0);
+    ch.slot = (int)(k % (size_t)plan.nslots);
+    Slot &sl = pl->slot[ch.slot];
+    int r;
+    if ((r = slot_stream(ctx, sl)) != DEGA_OK)
+      return r;
+    HIP_TRY(ctx, sl.a.need(ch.n * stride + 64), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.b.need(ch.n * cap + 64), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.meta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.hmeta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
+    MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
+    memcpy(hm.counts, in_len + ch.c0, ch.n * sizeof(uint64_t));
+    HIP_TRY(ctx, hipMemcpyAsync(dm.counts, hm.counts, ch.n * sizeof(uint64_t), hipMemcpyHostToDevice, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, in + ch.c0 * stride, ch.n * stride, ch.n * stride, 1, in_pinned), DEGA_ERROR_LIBRARY_CALL);
+    if ((r = dega_hip_lzmh_encode_dev(ctx, (const uint8_t *)sl.a.p, stride, dm.counts, ch.n, (uint8_t *)sl.b.p, cap, dm.bits, dm.err, sl.s)) != DEGA_OK)
+      return r;
+    hipLaunchKernelGGL(dega_offsets_kernel, dim3(1), dim3(1024), 0, sl.s, dm.bits, ch.n, dm.offsets);
+    HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, hipMemcpyAsync(sl.hmeta.p, sl.meta.p, (2 * ch.n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, hipMemcpyAsync(hm.err, dm.err, ch.n * sizeof(int32_t), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    return DEGA_OK;
+  };
+  auto stage2 = [&](size_t k) -> int {
+    Ch &ch = chunks[k];
+    Slot &sl = pl->slot[ch.slot];
+    MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
+    HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
+    const uint64_t tot = hm.offsets[ch.n];
+    for (size_t i = 0; i < ch.n; i++)
+    {
+      out_bits[ch.c0 + i] = hm.bits[i];
+      err[ch.c0 + i] = hm.err[i];
+      offsets[ch.c0 + i] = running + hm.offsets[i];
+    }
+    const uint64_t base = running;
+    running += tot;
+    if (running > packed_cap)
+      out_full = true; // keep sizing: the caller learns what it needs
+    if (out_full || tot == 0)
+      return DEGA_OK;
+    HIP_TRY(ctx, sl.c.need((size_t)tot + 64), DEGA_ERROR_MEMORY);
+    GatherArgs g{(const uint8_t *)sl.b.p, cap, dm.offsets, ch.n, (uint8_t *)sl.c.p};
+    hipLaunchKernelGGL(dega_gather_kernel, dim3((unsigned)((ch.n + WAVES - 1) / WAVES)), dim3(BLOCK), 0, sl.s, g);
+    HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, rows_to_host(pl, sl.s, packed + base, (size_t)tot, sl.c.p, (size_t)tot, 1, out_pinned), DEGA_ERROR_LIBRARY_CALL);
+    return DEGA_OK;
+  };
+  for (size_t k = 0; k < plan.nchunks + (size_t)plan.nslots; k++)
+  {
+    if (k >= (size_t)plan.nslots && (ret = stage2(k - (size_t)plan.nslots)) != DEGA_OK)
+      return ret;
+    if (k < plan.nchunks && (ret = stage1(k)) != DEGA_OK)
+      return ret;
+  }
+  HIP_TRY(ctx, pl->stager.drain(), DEGA_ERROR_LIBRARY_CALL);
+  for (int s = 0; s < plan.nslots; s++)
+    if (pl->slot[s].s != nullptr)
+      HIP_TRY(ctx, hipStreamSynchronize(pl->slot[s].s), DEGA_ERROR_LIBRARY_CALL);
+  offsets[C] = running;
+  *total_out = running;
+  if (out_full)
+    return fail(ctx, DEGA_ERROR_MEMORY, "packed buffer too small: offsets[C] holds the size needed", hipSuccess);
+  return DEGA_OK;
+}
+
+static int lzmh_decode_share(dega_hip_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride,
+                             uint64_t *out_len, int32_t *err)
+{
+  int ret;
+  Pipeline *pl;
+  HIP_TRY(ctx, hipSetDevice(ctx->device), DEGA_ERROR_LIBRARY_CALL);
+  if ((ret = pipeline_get(ctx, &pl)) != DEGA_OK)
+    return ret;
+  uint64_t longest_all = 0;
+  for (size_t c = 0; c < C; c++)
+    longest_all = std::max<uint64_t>(longest_all, offsets[c + 1] - offsets[c]);
+  const ChunkPlan plan = lzmh_plan(C, stride, (size_t)longest_all + 32);
+  const bool in_pinned = is_pinned(packed), out_pinned = is_pinned(out);
+  struct Ch
+  {
+    size_t c0, n;
+    int slot;
+  };
+  std::vector<Ch> chunks(plan.nchunks);
+  auto stage1 = [&](size_t k) -> int {
+    Ch &ch = chunks[k];
+    ch.c0 = k * plan.chunk_channels;
+    ch.n = std::min(plan.chunk_channels, C - ch.c0);
+    ch.slot = (int)(k % (size_t)plan.nslots);
+    Slot &sl = pl->slot[ch.slot];
+    int r;
+    if ((r = slot_stream(ctx, sl)) != DEGA_OK)
+      return r;
+    HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL); // the pinned mirror is about to be rewritten
+    const uint64_t o0 = offsets[ch.c0], nbytes = offsets[ch.c0 + ch.n] - o0;
+    uint64_t longest = 0;
+    for (size_t i = 0; i < ch.n; i++)
+      longest = std::max<uint64_t>(longest, offsets[ch.c0 + i + 1] - offsets[ch.c0 + i]);
+    const size_t cap = ((size_t)longest + 16 + 3) & ~(size_t)3;
+    HIP_TRY(ctx, sl.a.need((size_t)nbytes + 64), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.b.need(ch.n * cap + 64), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.c.need(ch.n * stride + 64), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.meta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
+    HIP_TRY(ctx, sl.hmeta.need(MetaView::bytes(ch.n)), DEGA_ERROR_MEMORY);
+    MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
+    for (size_t i = 0; i < ch.n; i++)
+    {
+      hm.bits[i] = in_bits[ch.c0 + i];
+      hm.offsets[i] = offsets[ch.c0 + i] - o0;
+    }
+    hm.offsets[ch.n] = nbytes;
+    HIP_TRY(ctx, hipMemcpyAsync(sl.meta.p, sl.hmeta.p, (2 * ch.n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, packed + o0, (size_t)nbytes, (size_t)nbytes, 1, in_pinned), DEGA_ERROR_LIBRARY_CALL);
+    GatherArgs g{(const uint8_t *)sl.b.p, cap, dm.offsets, ch.n, (uint8_t *)sl.a.p};
+    hipLaunchKernelGGL(dega_scatter_kernel, dim3((unsigned)((ch.n + WAVES - 1) / WAVES)), dim3(BLOCK), 0, sl.s, g);
+    HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
+    if ((r = dega_hip_lzmh_decode_dev(ctx, (const uint8_t *)sl.b.p, cap, dm.bits, ch.n, (uint8_t *)sl.c.p, stride, dm.counts, dm.err, sl.s)) != DEGA_OK)
+      return r;
+    HIP_TRY(ctx, hipMemcpyAsync(hm.counts, dm.counts, ch.n * sizeof(uint64_t) + ch.n * sizeof(int32_t), hipMemcpyDeviceToHost, sl.s), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, rows_to_host(pl, sl.s, out + ch.c0 * stride, ch.n * stride, sl.c.p, ch.n * stride, 1, out_pinned), DEGA_ERROR_LIBRARY_CALL);
+    return DEGA_OK;
+  };
+  auto stage2 = [&](size_t k) -> int {
+    Ch &ch = chunks[k];
+    Slot &sl = pl->slot[ch.slot];
+    HIP_TRY(ctx, pl->stager.drain(), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, hipStreamSynchronize(sl.s), DEGA_ERROR_LIBRARY_CALL);
+    MetaView hm(sl.hmeta.p, ch.n);
+    for (size_t i = 0; i < ch.n; i++)
+    {
+      out_len[ch.c0 + i] = hm.counts[i];
+      err[ch.c0 + i] = hm.err[i];
+    }
+    return DEGA_OK;
+  };
+  for (size_t k = 0; k < plan.nchunks + (size_t)plan.nslots; k++)
+  {
+    if (k >= (size_t)plan.nslots && (ret = stage2(k - (size_t)plan.nslots)) != DEGA_OK)
+      return ret;
+    if (k < plan.nchunks && (ret = stage1(k)) != DEGA_OK)
+      return ret;
+  }
+  return DEGA_OK;
+}
+
+static int lzmh_check(dega_hip_group *grp, size_t stride, bool encode)
+{
+  if (grp == nullptr || grp->ctx.empty())
+    return DEGA_ERROR_LIBRARY_INIT;
+  if (encode ? (stride == 0 || (stride & 15u) != 0 || stride > 0x7FFFFFF0u) : (stride < 8 || (stride & 7u) != 0))
+  {
+    snprintf(grp->last_error, sizeof(grp->last_error), encode ? "lzmh encode: stride must be a multiple of 16" : "lzmh decode: stride must be a multiple of 8");
+    return DEGA_ERROR_INVALID_VALUE;
+  }
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_group_lzmh_encode(dega_hip_group *grp, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *packed,
+                                          size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err)
+{
+  int ret;
+  if ((ret = lzmh_check(grp, stride, true)) != DEGA_OK)
+    return ret;
+  if (offsets == nullptr || out_bits == nullptr || err == nullptr || in_len == nullptr || (in == nullptr && C != 0) || (packed == nullptr && packed_cap != 0))
+    return DEGA_ERROR_INVALID_VALUE;
+  offsets[0] = 0;
+  if (C == 0)
+    return DEGA_OK;
+  const size_t G = std::max<size_t>(1, std::min<size_t>(grp->ctx.size(), (C + 255) / 256));
+  uint64_t total = 0;
+  if (G == 1)
+  {
+    ret = lzmh_encode_share(grp->ctx[0], in, stride, in_len, C, packed, packed_cap, offsets, out_bits, err, &total);
+    return ret == DEGA_OK ? DEGA_OK : group_fail(grp, ret, grp->ctx[0], 0);
+  }
+  // every device codes its range of channels into a buffer of its own; the host puts them behind one another
+  std::vector<size_t> cut(G + 1, 0);
+  for (size_t g = 1; g < G; g++)
+    cut[g] = (C / G * g + std::min(C % G, g)) / 256 * 256;
+  cut[G] = C;
+  std::vector<std::vector<uint8_t>> tmp(G);
+  std::vector<std::vector<uint64_t>> rel(G);
+  std::vector<uint64_t> tot(G, 0);
+  std::vector<int> rets(G, DEGA_OK);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; g++)
+    th.emplace_back([&, g] {
+      const size_t n = cut[g + 1] - cut[g];
+      uint64_t text = 0;
+      for (size_t i = 0; i < n; i++)
+        text += in_len[cut[g] + i];
+      tmp[g].resize((size_t)(text + text / 4 + 64 * n + 64)); // a stream is at most 10 bits per byte of text
+      rel[g].assign(n + 1, 0);
+      rets[g] = n == 0 ? DEGA_OK
+                       : lzmh_encode_share(grp->ctx[g], in + cut[g] * stride, stride, in_len + cut[g], n, tmp[g].data(), tmp[g].size(), rel[g].data(),
+                                           out_bits + cut[g], err + cut[g], &tot[g]);
+    });
+  for (std::thread &t : th)
+    t.join();
+  for (size_t g = 0; g < G; g++)
+    if (rets[g] != DEGA_OK)
+      return group_fail(grp, rets[g], grp->ctx[g], g);
+  uint64_t base = 0;
+  for (size_t g = 0; g < G; g++)
+  {
+    for (size_t i = 0; i < cut[g + 1] - cut[g]; i++)
+      offsets[cut[g] + i] = base + rel[g][i];
+    if (base + tot[g] <= packed_cap && tot[g] > 0)
+      memcpy(packed + base, tmp[g].data(), (size_t)tot[g]);
+    base += tot[g];
+  }
+  offsets[C] = base;
+  if (base > packed_cap)
+  {
+    snprintf(grp->last_error, sizeof(grp->last_error), "packed buffer too small: offsets[C] holds the size needed");
+    return DEGA_ERROR_MEMORY;
+  }
+  return DEGA_OK;
+}
+
+extern "C" int dega_hip_group_lzmh_decode(dega_hip_group *grp, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, uint8_t *out,
+                                          size_t stride, uint64_t *out_len, int32_t *err)
+{
+  int ret;
+  if ((ret = lzmh_check(grp, stride, false)) != DEGA_OK)
+    return ret;
+  if (offsets == nullptr || in_bits == nullptr || out_len == nullptr || err == nullptr || (out == nullptr && C != 0))
+    return DEGA_ERROR_INVALID_VALUE;
+  if (C == 0)
+    return DEGA_OK;
+  for (size_t c = 0; c < C; c++)
+    if (offsets[c + 1] < offsets[c] || in_bits[c] / 8 > offsets[c + 1] - offsets[c] || (in_bits[c] / 8 == offsets[c + 1] - offsets[c] && (in_bits[c] & 7) != 0) ||
+        offsets[c + 1] - offsets[c] > ((uint64_t)1 << 31))
+    {
+      snprintf(grp->last_error, sizeof(grp->last_error), "offsets must grow and hold ceil(bits / 8) bytes per channel");
+      return DEGA_ERROR_INVALID_VALUE;
+    }
+  const size_t G = std::max<size_t>(1, std::min<size_t>(grp->ctx.size(), (C + 255) / 256));
+  std::vector<size_t> cut(G + 1, 0);
+  for (size_t g = 1; g < G; g++)
+    cut[g] = (C / G * g + std::min(C % G, g)) / 256 * 256;
+  cut[G] = C;
+  std::vector<int> rets(G, DEGA_OK);
+  auto work = [&](size_t g) {
+    const size_t n = cut[g + 1] - cut[g];
+    if (n != 0)
+      rets[g] = lzmh_decode_share(grp->ctx[g], packed, offsets + cut[g], in_bits + cut[g], n, out + cut[g] * stride, stride, out_len + cut[g], err + cut[g]);
+  };
+  if (G == 1)
+    work(0);
+  else
+  {
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++)
+      th.emplace_back(work, g);
+    for (std::thread &t : th)
+      t.join();
+  }
+  for (size_t g = 0; g < G; g++)
+    if (rets[g] != DEGA_OK)
+      return group_fail(grp, rets[g], grp->ctx[g], g);
+  return DEGA_OK;
+}

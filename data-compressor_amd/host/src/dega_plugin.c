@@ -489,18 +489,16 @@ io_int_t EncodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
   FILE *const log = options->error_log_file;
   const size_t C = channels_of(options);
   dega_hip_group *group;
-  dega_hip_ctx *ctx;
   byte_vec raw = { NULL, 0, 0 };
   uint64_t nbits = 0, total;
-  uint64_t *in_len = NULL, *out_bits = NULL;
+  uint64_t *in_len = NULL, *out_bits = NULL, *offsets = NULL;
   uint8_t *in = NULL, *out = NULL;
   int32_t *err = NULL;
-  size_t stride, cap, piece, c;
+  size_t stride, out_cap, piece, c;
   io_int_t ret;
 
   if ((ret = get_group(log, &group)) != NO_ERROR)
     return ret;
-  ctx = dega_hip_group_context(group, 0);
   if ((ret = slurp(in_bit_buf, &raw, &nbits)) != NO_ERROR)
     goto done;
   if (nbits % 8 != 0) /* the reference's READ_VALUE_BITS_CHECKED(8) would stop on the short last byte (lzmh.c:163) */
@@ -512,12 +510,15 @@ io_int_t EncodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
   total = nbits / 8;
   piece = C > 1 ? (size_t)((total + C - 1) / C) : (size_t)total; /* one channel = the whole input, as the reference codes it */
   stride = (piece + 16) / 16 * 16;
-  cap = dega_hip_lzmh_worst_case_bytes(stride);
+  /* the streams come back packed, one behind the other (a stream is at most 10 bits per byte of text): every visible GPU
+     codes a range of the pieces, the library's host pipeline overlaps copies and kernels (dega_hip_group_lzmh_encode) */
+  out_cap = (size_t)(total + total / 4) + 64 * C + 64;
   in_len = (uint64_t *)calloc(C, sizeof(uint64_t));
   out_bits = (uint64_t *)calloc(C, sizeof(uint64_t));
+  offsets = (uint64_t *)calloc(C + 1, sizeof(uint64_t));
   err = (int32_t *)calloc(C, sizeof(int32_t));
-  if (in_len == NULL || out_bits == NULL || err == NULL || mul_or_zero(C, cap) == 0 || posix_memalign((void **)&in, 16, C * stride) != 0 ||
-      posix_memalign((void **)&out, 16, C * cap) != 0)
+  if (in_len == NULL || out_bits == NULL || offsets == NULL || err == NULL || mul_or_zero(C, stride) == 0 || posix_memalign((void **)&in, 16, C * stride) != 0 ||
+      (out = (uint8_t *)malloc(out_cap)) == NULL)
   {
     ret = ERROR_MEMORY;
     goto done;
@@ -530,9 +531,9 @@ io_int_t EncodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
     if (in_len[c] > 0)
       memcpy(in + c * stride, raw.p + at, (size_t)in_len[c]);
   }
-  if ((ret = dega_hip_lzmh_encode_host(ctx, in, stride, in_len, C, out, cap, out_bits, err)) != DEGA_OK)
+  if ((ret = dega_hip_group_lzmh_encode(group, in, stride, in_len, C, out, out_cap, offsets, out_bits, err)) != DEGA_OK)
   {
-    LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_last_error(ctx));
+    LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_group_last_error(group));
     goto done;
   }
   if ((ret = first_error(err, C, log, "encoding")) != NO_ERROR)
@@ -558,12 +559,8 @@ io_int_t EncodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
       if (WriteBitFileBuffer(out_bit_buf, head, 128) != 128)
         ret = ERROR_LIBRARY_CALL;
     }
-    for (c = 0; c < C && ret == NO_ERROR; c++)
-    {
-      const size_t nb = (size_t)((out_bits[c] + 7) / 8) * 8;
-      if (WriteBitFileBuffer(out_bit_buf, out + c * cap, nb) != (io_int_t)nb)
-        ret = ERROR_LIBRARY_CALL;
-    }
+    if (ret == NO_ERROR && offsets[C] > 0 && WriteBitFileBuffer(out_bit_buf, out, (size_t)offsets[C] * 8) != (io_int_t)(offsets[C] * 8))
+      ret = ERROR_LIBRARY_CALL; /* the streams, each padded to a whole byte, exactly as the library packed them */
   }
 done:
   free(raw.p);
@@ -571,6 +568,7 @@ done:
   free(out);
   free(in_len);
   free(out_bits);
+  free(offsets);
   free(err);
   return ret;
 }
@@ -579,19 +577,17 @@ io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
 {
   FILE *const log = options->error_log_file;
   dega_hip_group *group;
-  dega_hip_ctx *ctx;
   byte_vec raw = { NULL, 0, 0 };
   uint64_t nbits = 0;
-  uint64_t *in_bits = NULL, *want_len = NULL, *out_len = NULL;
-  uint8_t *in = NULL, *out = NULL;
+  uint64_t *in_bits = NULL, *want_len = NULL, *out_len = NULL, *offsets = NULL;
+  uint8_t *out = NULL;
   int32_t *err = NULL;
-  size_t C = 1, cap = 0, stride, c, at;
+  size_t C = 1, stride, c, at;
   int attempt, container = 0;
   io_int_t ret;
 
   if ((ret = get_group(log, &group)) != NO_ERROR)
     return ret;
-  ctx = dega_hip_group_context(group, 0);
   if ((ret = slurp(in_bit_buf, &raw, &nbits)) != NO_ERROR)
     goto done;
   if (channels_of(options) > 1)
@@ -615,14 +611,15 @@ io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
   want_len = (uint64_t *)calloc(C, sizeof(uint64_t));
   out_len = (uint64_t *)calloc(C, sizeof(uint64_t));
   err = (int32_t *)calloc(C, sizeof(int32_t));
-  if (in_bits == NULL || want_len == NULL || out_len == NULL || err == NULL)
+  offsets = (uint64_t *)calloc(C + 1, sizeof(uint64_t));
+  if (in_bits == NULL || want_len == NULL || out_len == NULL || err == NULL || offsets == NULL)
   {
     ret = ERROR_MEMORY;
     goto done;
   }
   if (container)
   {
-    uint64_t longest = 0, longest_text = 0, sum = 0;
+    uint64_t longest_text = 0, sum = 0;
     const uint64_t room = (uint64_t)raw.n - 16 - 16 * (uint64_t)C;
     for (c = 0; c < C; c++)
     {
@@ -634,37 +631,26 @@ io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
         ret = ERROR_INVALID_FORMAT;
         goto done;
       }
+      offsets[c] = sum; /* the streams lie packed in the container, each padded to a whole byte: used where they are */
       sum += (in_bits[c] + 7) / 8;
-      longest = (in_bits[c] + 7) / 8 > longest ? (in_bits[c] + 7) / 8 : longest;
       longest_text = want_len[c] > longest_text ? want_len[c] : longest_text;
     }
+    offsets[C] = sum;
     if (sum > room)
     {
       ret = ERROR_INVALID_FORMAT;
       goto done;
     }
-    cap = ((size_t)longest + 8) / 4 * 4;
     stride = ((size_t)longest_text + 8 + 7) / 8 * 8;
   }
   else
   {
     in_bits[0] = nbits;
-    cap = (raw.n + 8) / 4 * 4;
+    offsets[1] = (nbits + 7) / 8;
     /* a bare LZMH stream does not say how long its text is: start from 4x and grow while the row overflows */
     stride = (4 * raw.n + 4096) / 8 * 8;
   }
-  if (mul_or_zero(C, cap) == 0 || (in = (uint8_t *)calloc(C, cap)) == NULL)
-  {
-    ret = ERROR_MEMORY;
-    goto done;
-  }
   at = container ? 16 + 16 * C : 0;
-  for (c = 0; c < C; c++)
-  {
-    const size_t nb = (size_t)((in_bits[c] + 7) / 8);
-    memcpy(in + c * cap, raw.p + at, container ? nb : raw.n);
-    at += nb;
-  }
   for (attempt = 0;; attempt++)
   {
     free(out);
@@ -673,9 +659,9 @@ io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
       ret = ERROR_MEMORY;
       goto done;
     }
-    if ((ret = dega_hip_lzmh_decode_host(ctx, in, cap, in_bits, C, out, stride, out_len, err)) != DEGA_OK)
+    if ((ret = dega_hip_group_lzmh_decode(group, raw.p + at, offsets, in_bits, C, out, stride, out_len, err)) != DEGA_OK)
     {
-      LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_last_error(ctx));
+      LOG_TO(log, "glzmh: %s (%s)\n", ERROR_MESSAGE_STRING(ret), dega_hip_group_last_error(group));
       goto done;
     }
     if (container || err[0] != ERROR_MEMORY || attempt == 5)
@@ -696,11 +682,11 @@ io_int_t DecodeLZMHGPU(bit_file_buffer_t *const in_bit_buf, bit_file_buffer_t *c
   }
 done:
   free(raw.p);
-  free(in);
   free(out);
   free(in_bits);
   free(want_len);
   free(out_len);
+  free(offsets);
   free(err);
   return ret;
 }

@@ -155,6 +155,14 @@ int dega_hip_lzmh_encode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t strid
                               uint64_t *out_bits, int32_t *err);
 int dega_hip_lzmh_decode_host(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, uint8_t *out, size_t stride,
                               uint64_t *out_len, int32_t *err);
+/* The same for a group, through the host pipeline: chunks of channels on their own streams (upload, kernel, pack, download
+   overlapped), contiguous channel ranges per device, streams packed back to back: channel c at packed[offsets[c] ..
+   offsets[c+1]) (C + 1 offsets, ceil(bits / 8) bytes each).  Host memory; pinned memory is used in place.  encode returns
+   ERROR_MEMORY with the size needed in offsets[C] when packed_cap is too small; stride as for the _dev forms. */
+int dega_hip_group_lzmh_encode(dega_hip_group *group, const uint8_t *in, size_t stride, const uint64_t *in_len, size_t C, uint8_t *packed,
+                               size_t packed_cap, uint64_t *offsets, uint64_t *out_bits, int32_t *err);
+int dega_hip_group_lzmh_decode(dega_hip_group *group, const uint8_t *packed, const uint64_t *offsets, const uint64_t *in_bits, size_t C, uint8_t *out,
+                               size_t stride, uint64_t *out_len, int32_t *err);
 
 /* ---- float entry / exit fused into the coder kernels, device pointers ----------------------------------- */
 /* v_tc: float32 [T][ld].  One launch: Normalize on each value as it enters the fill phase (normalize.c:16-24; a value

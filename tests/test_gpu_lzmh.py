@@ -176,3 +176,50 @@ def test_lzmh_long_channels_count_saturation_and_long_runs(ctx):
     for i, s in enumerate(strings[:3]):
         assert int(lens[i]) == len(s) and dec[i, : len(s)].tobytes() == s, i
     assert int(lens[3]) == 1  # the reference's decoder turns the empty stream into one zero byte (lzmh.json: digits_0)
+
+
+def test_lzmh_group_pipeline_packs_and_splits(dca, ctx):
+    """dega_hip_group_lzmh_encode / _decode: the host pipeline (chunks of channels on their own streams, packed streams
+    back) on a group of one and of two members (with one visible GPU both share device 0: the partition, the threads and
+    the host-side concatenate are the same code): the packed streams are the single-context slab call's, byte for byte,
+    and decode to the text; pageable and pinned memory; a packed buffer too small reports the size needed."""
+    rng = np.random.default_rng(321)
+    strings = make_strings(rng, 1100, 900)  # more than two 512-channel chunks
+    Cn = len(strings)
+    stride = (max(len(s) for s in strings) + 16) // 16 * 16
+    text = np.zeros((Cn, stride), dtype=np.uint8)
+    lens = np.array([len(s) for s in strings], dtype=np.uint64)
+    for i, s in enumerate(strings):
+        text[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    want_out, want_bits, want_err = ctx.lzmh_encode_host(strings)
+    assert (want_err == 0).all()
+    want_back, want_lens, want_derr = ctx.lzmh_decode_host(want_out, want_bits, stride)
+    assert (want_derr == 0).all()
+    os.environ["DEGA_PIPELINE_CHUNKS"] = "3"
+    try:
+        for devices in ([0], [0, 0]):
+            g = dca.Group(devices)
+            try:
+                pinned = dca.PinnedArray((Cn, stride), np.uint8)
+                pinned.array[:] = text
+                for src in (text, pinned.array):
+                    packed, offsets, bits, err = g.lzmh_encode_job(src, lens)
+                    assert (err == 0).all() and (bits == want_bits).all()
+                    assert int(offsets[0]) == 0 and (np.diff(offsets.astype(np.int64)) == (bits.astype(np.int64) + 7) // 8).all()
+                    for c in range(Cn):
+                        nb = (int(bits[c]) + 7) // 8
+                        assert packed[int(offsets[c]): int(offsets[c]) + nb].tobytes() == want_out[c, :nb].tobytes(), (devices, c)
+                    back, blens, berr = g.lzmh_decode_job(packed, offsets, bits, stride)
+                    assert (berr == 0).all() and (blens == want_lens).all()  # (the codec's quirks included: an empty stream decodes to one byte)
+                    for c in range(Cn):
+                        assert back[c, : int(want_lens[c])].tobytes() == want_back[c, : int(want_lens[c])].tobytes(), (devices, c)
+                        assert len(strings[c]) in (0, 403) or back[c, : len(strings[c])].tobytes() == strings[c], (devices, c)
+                pinned.free()
+                small = np.empty(100, dtype=np.uint8)
+                with pytest.raises(dca.DegaError) as e:
+                    g.lzmh_encode_job(text, lens, packed=small)
+                assert e.value.code == -6
+            finally:
+                g.close()
+    finally:
+        del os.environ["DEGA_PIPELINE_CHUNKS"]
