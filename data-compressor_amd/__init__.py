@@ -77,6 +77,8 @@ _SIGNATURES = {
     "dega_hip_group_last_error": (C.c_char_p, [_P]),
     "dega_hip_group_encode": (C.c_int, [_P, _P, _P, _P, _Z, _P, _P, _P]),
     "dega_hip_group_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "dega_hip_encode_state_bytes": (C.c_size_t, [C.c_size_t]),
+    "dega_hip_encode_segment_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, C.c_uint, _P]),
     "dega_hip_group_lzmh_encode": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P]),
     "dega_hip_group_lzmh_decode": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, _P]),
     "dega_hip_pinned_alloc": (_P, [_Z]),
@@ -339,6 +341,27 @@ class Context(_JobCalls):
         ret = library().dega_hip_encode_dev(self._h, x_tc.data_ptr(), Cn, T, ld, int(adaptive), int(valuesize), out.data_ptr(), cap,
                                             bits.data_ptr(), err.data_ptr(), self._stream())
         self._check(ret, "dega_hip_encode_dev")
+        return out, bits, err
+
+    def encode_segments(self, x_tc, cuts, adaptive=1, cap=None, valuesize=32):
+        """The rows of x_tc ([T, C] int32 CUDA tensor) coded in ranges [cuts[k], cuts[k+1]), one launch each, the lanes' state
+        kept in device memory in between (dega_hip_encode_segment_dev).  Returns (out, bits, err) of the whole channels."""
+        import torch
+        T, Cn = x_tc.shape
+        assert x_tc.dtype == torch.int32 and x_tc.is_cuda and x_tc.is_contiguous() and cuts[0] == 0 and cuts[-1] == T
+        if cap is None:
+            cap = worst_case_bytes(T)
+        out = torch.zeros((Cn, cap), dtype=torch.uint8, device=x_tc.device)
+        bits = torch.zeros(Cn, dtype=torch.int64, device=x_tc.device)
+        err = torch.zeros(Cn, dtype=torch.int32, device=x_tc.device)
+        state = torch.zeros(library().dega_hip_encode_state_bytes(Cn), dtype=torch.uint8, device=x_tc.device)
+        for k in range(len(cuts) - 1):
+            flags = (1 if k > 0 else 0) | (2 if k + 2 < len(cuts) else 0)
+            rows = x_tc[cuts[k]:cuts[k + 1]]
+            ptr = rows.data_ptr() if cuts[k + 1] > cuts[k] else x_tc.data_ptr()
+            ret = library().dega_hip_encode_segment_dev(self._h, ptr, Cn, cuts[k + 1] - cuts[k], Cn, int(adaptive), int(valuesize), out.data_ptr(), cap,
+                                                        bits.data_ptr(), err.data_ptr(), state.data_ptr(), flags, self._stream())
+            self._check(ret, "dega_hip_encode_segment_dev")
         return out, bits, err
 
     def decode(self, streams, bits, T, adaptive=1, x_tc=None, err=None, valuesize=32):

@@ -452,6 +452,24 @@ extern "C" int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_
   return launch_encode(ctx, x_tc, shape_of(C, T, ld, adaptive, valuesize, DEGA_SAMPLES_I32), C, out, cap, out_bits, err, (hipStream_t)stream);
 }
 
+extern "C" size_t dega_hip_encode_state_bytes(size_t C)
+{
+  return (size_t)ENC_STATE_WORDS * C * sizeof(uint32_t);
+}
+
+extern "C" int dega_hip_encode_segment_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T_seg, size_t ld, int adaptive, int valuesize,
+                                           uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *state, unsigned flags, void *stream)
+{
+  int ret;
+  if ((ret = check_shape(ctx, C, T_seg, ld, cap, valuesize)) != DEGA_OK)
+    return ret;
+  if (state == nullptr || (flags & ~(unsigned)(DEGA_SEGMENT_CONTINUES | DEGA_SEGMENT_MORE)) != 0u || ((uintptr_t)state & 3u) != 0)
+    return fail(ctx, DEGA_ERROR_INVALID_VALUE, "encode segment: state (device memory, dega_hip_encode_state_bytes) and flags DEGA_SEGMENT_*", hipSuccess);
+  static_assert(DEGA_SEGMENT_CONTINUES == ENC_SEG_CONTINUES && DEGA_SEGMENT_MORE == ENC_SEG_MORE, "the flags of the header are the kernel's");
+  return launch_encode(ctx, x_tc, shape_of(C, T_seg, ld, adaptive, valuesize, DEGA_SAMPLES_I32), C, out, cap, out_bits, err, (hipStream_t)stream,
+                       (uint32_t *)state, flags);
+}
+
 extern "C" int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,
                                    int adaptive, int valuesize, int32_t *x_tc, int32_t *err, void *stream)
 {

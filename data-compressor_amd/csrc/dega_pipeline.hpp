@@ -524,7 +524,7 @@ static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes
     n = 1;
   size_t cc = (C + n - 1) / n;
   if (n > 1)
-    cc = std::max<size_t>((cc + 511) / 512 * 512, std::min<size_t>(C, 8192)); // rows of a chunk: 32 KiB or more (copies of narrow rows are slow)
+    cc = std::max<size_t>((cc + 511) / 512 * 512, std::min<size_t>(C, 8192)); // rows of a chunk: 32 KiB or more (copies of narrow rows are slow: two chunks of 4 096 channels took 81 ms where one of 8 192 takes 66)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
     free_b = (size_t)8 << 30;
@@ -542,9 +542,9 @@ static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes
 
 // Rows per band when a chunk's samples cross the link in bands (0: in one piece, the usual way): encode codes every band
 // with a launch of its own as soon as it has landed -- plain stream order, an event per band; nothing on the device ever
-// waits for the host -- and decode sends every band home as soon as all waves have stored it.  Only worth it when there
-// are too few chunks to overlap one chunk's copy with another's kernel and the channels are long; bands end on multiples
-// of 32 rows (whole 128-byte lines of the device array) and are about 32 MiB each.
+// waits for the host -- and decode sends every band home as soon as all waves have stored it.  Worth it when the channels
+// are long (a launch per band has its fixed costs); bands end on multiples of 32 rows (whole 128-byte lines of the device
+// array) and are about 32 MiB each.
 static size_t band_rows_of(const ChunkPlan &plan, const Shape &j, size_t row_bytes)
 {
   size_t band_bytes = (size_t)32 << 20, min_T = 4096;
@@ -553,7 +553,9 @@ static size_t band_rows_of(const ChunkPlan &plan, const Shape &j, size_t row_byt
     band_bytes = (size_t)strtoull(e, nullptr, 10);
     min_T = 64;
   }
-  if (band_bytes == 0 || plan.nchunks > 2 || j.T < min_T || row_bytes == 0)
+  (void)plan; // (any number of chunks: a chunk's kernels start with its first band, so only the last band's kernel and the
+              //  last chunk's download are left over when the last byte has gone up)
+  if (band_bytes == 0 || j.T < min_T || row_bytes == 0)
     return 0;
   size_t rows = std::max<size_t>(band_bytes / row_bytes, 32);
   rows = (rows + 31) / 32 * 32;
@@ -1144,16 +1146,24 @@ static int encode_on_group(dega_hip_group *grp, const Shape &j, const void *samp
     ret = encode_share(grp->ctx[0], j, samples, sink, true, run);
     return ret == DEGA_OK ? DEGA_OK : group_fail(grp, ret, grp->ctx[0], 0);
   }
-  // Rounds: what the devices can hold at once (samples + slabs resident until the sizes in front are known)
-  size_t free_b = 0, total_b = 0;
-  (void)hipSetDevice(grp->ctx[0]->device);
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
-    free_b = (size_t)64 << 30;
-  const size_t per_channel = j.T * esz + usual_cap(j) + 256;
-  const size_t round_channels = std::max<size_t>(G * 512, std::min<size_t>(j.C, free_b / 10 * 6 / per_channel * G / 512 * 512));
+  // Rounds: what the devices can hold at once (samples + slabs resident until the sizes in front are known) -- by the
+  // member with the least free memory, and with the bytes per channel that encode_share reserves
+  size_t free_b = ~(size_t)0;
+  for (size_t g = 0; g < G; g++)
+  {
+    size_t f = 0, t = 0;
+    if (hipSetDevice(grp->ctx[g]->device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      f = (size_t)64 << 30;
+    }
+    free_b = std::min(free_b, f);
+  }
+  const size_t per_channel = std::max(j.T * esz + 64, usual_cap(j)) + 16 + usual_cap(j) + 64 + 256;
+  size_t round_channels = std::max<size_t>(G * 512, std::min<size_t>(j.C, free_b / 10 * 6 / per_channel * G / 512 * 512));
   uint64_t base = 0;
   bool out_full = false;
-  for (size_t r0 = 0; r0 < j.C; r0 += round_channels)
+  for (size_t r0 = 0; r0 < j.C;)
   {
     const size_t rC = std::min(round_channels, j.C - r0);
     const std::vector<size_t> cut = split_channels(rC, G);
@@ -1174,6 +1184,17 @@ static int encode_on_group(dega_hip_group *grp, const Shape &j, const void *samp
       });
     for (std::thread &t : th)
       t.join();
+    {
+      // a member that cannot keep its share resident after all (another process took memory meanwhile): a smaller round
+      bool too_big = false;
+      for (size_t g = 0; g < G; g++)
+        too_big = too_big || (rets[g] == DEGA_ERROR_MEMORY && round_channels > G * 512);
+      if (too_big)
+      {
+        round_channels = std::max<size_t>(G * 512, round_channels / 2 / 512 * 512);
+        continue;
+      }
+    }
     for (size_t g = 0; g < G; g++)
       if (rets[g] != DEGA_OK)
         return group_fail(grp, rets[g], grp->ctx[g], g);
@@ -1190,7 +1211,10 @@ static int encode_on_group(dega_hip_group *grp, const Shape &j, const void *samp
     if (sink.slabs == nullptr && base > sink.packed_cap)
       out_full = true;
     if (out_full)
+    {
+      r0 += rC;
       continue; // keep sizing
+    }
     th.clear();
     std::vector<std::vector<uint8_t>> tmp(G);
     for (size_t g = 0; g < G; g++)
@@ -1216,6 +1240,7 @@ static int encode_on_group(dega_hip_group *grp, const Shape &j, const void *samp
     for (size_t g = 0; g < G; g++)
       if (rets[g] != DEGA_OK)
         return group_fail(grp, rets[g], grp->ctx[g], g);
+    r0 += rC;
   }
   if (sink.offsets != nullptr)
     sink.offsets[j.C] = base;

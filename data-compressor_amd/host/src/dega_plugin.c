@@ -444,6 +444,9 @@ static io_int_t decode_common(bit_file_buffer_t *const in, bit_file_buffer_t *co
     }
     break;
   }
+  if (!known_T && err[0] == ERROR_MEMORY && T >= DEGA_PLUGIN_MAX_T)
+    LOG_TO(log, "dega: the stream holds more than %lu samples, the most one channel may have per call of the library (the reference has no such limit: "
+                "split the series, or code it as a batch with num_channels)\n", (unsigned long)DEGA_PLUGIN_MAX_T);
   if ((ret = first_error(err, C, log, "decoding")) != NO_ERROR)
     goto done;
   if (!known_T)

@@ -86,6 +86,20 @@ size_t dega_hip_worst_case_bytes(size_t T);
    decoder caps a codeword's zero prefix at valuesize + 1 (seg.c:55-56,74).  33..64: the *64 entry points below.  adaptive: 0 = `bac`, 1 = `bac adaptive`. */
 int dega_hip_encode_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T, size_t ld, int adaptive, int valuesize,
                         uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *stream);
+/* The same over several calls, each taking the next T_seg rows of the channels (x_tc = the first of them): a channel's
+   encoder state -- bit queue, interval and model of EncodeBAC (bac.c:33-37,83-84: the statics a reference process holds
+   between symbols), finished bits, the held-back word -- is saved to `state` (dega_hip_encode_state_bytes(C) bytes of
+   device memory, owned by the caller, opaque) when flags has DEGA_SEGMENT_MORE and picked up when it has
+   DEGA_SEGMENT_CONTINUES; out / cap / out_bits / err as above, the same in every call, final after the last one (the
+   one without DEGA_SEGMENT_MORE; T_seg = 0 is allowed there).  The streams are those of one call over all the rows.
+   This is how the host pipeline codes a batch of few, long channels while its rows are still arriving (one call per
+   band of rows, each behind its band's copy in plain stream order), and how a caller codes series of more than 2^25
+   samples. */
+#define DEGA_SEGMENT_CONTINUES 1
+#define DEGA_SEGMENT_MORE 2
+size_t dega_hip_encode_state_bytes(size_t C);
+int dega_hip_encode_segment_dev(dega_hip_ctx *ctx, const int32_t *x_tc, size_t C, size_t T_seg, size_t ld, int adaptive, int valuesize,
+                                uint8_t *out, size_t cap, uint64_t *out_bits, int32_t *err, void *state, unsigned flags, void *stream);
 /* in_bits[c] is the exact bit length, or 8*bytes when the stream comes from a zero-padded file.  Decodes exactly T
    samples per channel; a stream holding fewer or more yields DEGA_ERROR_INVALID_FORMAT for that channel. */
 int dega_hip_decode_dev(dega_hip_ctx *ctx, const uint8_t *in, size_t cap, const uint64_t *in_bits, size_t C, size_t T, size_t ld,

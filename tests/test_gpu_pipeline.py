@@ -387,3 +387,34 @@ def test_reference_dccli_codes_a_batch_of_channels(tmp_path):
     assert p.returncode == 0 and dec.read_bytes() == text
     # the reference's parser knows the option now -- and still refuses it on a row that does not list it
     assert ref_cli([str(src), str(enc), "encode", "diff", "num_channels=4"]).returncode != 0
+
+
+@pytest.mark.gpu
+def test_channels_coded_over_several_launches(ctx):
+    """dega_hip_encode_segment_dev: the rows of a batch in ranges, one launch per range, the lanes' state saved in device
+    memory in between -- what the host pipeline does with the bands of a few-long-channels batch.  The streams are those
+    of one launch over all rows (= the oracle's): cuts inside a seg-bit word, single-row ranges, an empty last range,
+    channels out of range from the start and from the middle, both models, a narrow value size, a ragged wave."""
+    import torch
+    rng = np.random.default_rng(77)
+    T, Cn = 5000, 700
+    x = (np.cumsum(rng.integers(-300, 301, (T, Cn)), axis=0) + 1000000).astype(np.int32)
+    x[2000:, 5] = -7
+    x[0, 6] = -1
+    xd = torch.from_numpy(x).cuda()
+    for ad, vs in ((1, 32), (0, 32), (1, 24)):
+        xs = x if vs == 32 else (x & ((1 << vs) - 1))
+        want_out, want_bits, want_err = ctx.encode(torch.from_numpy(xs).cuda(), adaptive=ad, valuesize=vs)
+        torch.cuda.synchronize()
+        if vs == 32:  # the one-launch streams are the oracle's (pinned elsewhere for the other value sizes)
+            o2, b2, e2 = orc.encode_batch_tc(x, ad, cap=want_out.shape[1])
+            assert (want_err.cpu().numpy() == e2).all() and (want_bits.cpu().numpy().astype(np.uint64)[e2 == 0] == b2[e2 == 0]).all()
+        for cuts in ([0, 1, 2, 2500, 2501, 4999, 5000], [0, 1024, 2048, 3072, 4096, 5000, 5000], [0, 5000]):
+            out, bits, err = ctx.encode_segments(torch.from_numpy(xs).cuda() if vs != 32 else xd, cuts, adaptive=ad, cap=want_out.shape[1], valuesize=vs)
+            torch.cuda.synchronize()
+            assert (err == want_err).all(), (ad, vs, cuts)
+            ok = (want_err == 0)
+            assert (bits[ok] == want_bits[ok]).all(), (ad, vs, cuts)
+            nb = ((want_bits + 7) // 8)
+            idx = torch.arange(want_out.shape[1], device=out.device)[None, :] < nb[:, None]
+            assert bool((((out == want_out) | ~idx)[ok]).all()), (ad, vs, cuts)
