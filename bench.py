@@ -31,11 +31,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
-# The model behind roofline.issue_bound_ms: VALU instructions of the unrolled symbol step (ISA count of the
-# shipped kernel, csrc/Makefile `asm`), cycles per wave instruction of a SIMD (profiles/r01_ubench_issue_cost.txt) and the
-# shader clock under this load.
-ISSUE_INSTR_PER_SYMBOL = 26.7  # 853 VALU instructions per 32-symbol word: 23.5 per symbol + (dump + hand-over) per 8 symbols
-ISSUE_CYCLES_PER_INSTR = 4.0   # a SIMD issues one wave64 VALU instruction per 4 cycles (two waves resident: coding + filling)
+# The model behind roofline.issue_bound_ms: what bounds a channel is the instruction stream of ITS coding wave --
+# one wave issues an instruction every 4.09 (4-byte encodings) to 4.56 (8-byte) cycles whatever shares the SIMD with it
+# (profiles/r03_ubench2_issue_cost.txt).  Instructions of a steady 32-symbol step of that wave from the ISA ledger
+# (profiles/r03_isa_ledger.md): 698 VALU + 19 LDS + 26 SALU.
+ISSUE_INSTR_PER_SYMBOL = 743.0 / 32.0
+ISSUE_CYCLES_PER_INSTR = 4.3   # the mix of 4- and 8-byte encodings of the word path
 SHADER_CLOCK_HZ = 2.25e9
 
 
@@ -390,12 +391,12 @@ def run_dega(env, args):
             res["cpu_baseline"] = cpu_baseline(xs, out[:n].cpu().numpy(), bits[:n].cpu().numpy(), 1)
             res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
             # what the kernel really runs against: every channel is a serial chain of coded symbols, 64 Ki channels are one
-            # coding wave per SIMD, and a SIMD issues one instruction of it per 4 cycles: a launch cannot finish before the
+            # coding wave per SIMD, and a wave issues one instruction per ~4.3 cycles: a launch cannot finish before the
             # longest chain has been issued
             sym = seg_symbols_per_sample(xs)
             issue_ms = T * sym * ISSUE_INSTR_PER_SYMBOL * ISSUE_CYCLES_PER_INSTR / SHADER_CLOCK_HZ * 1e3
             res["roofline"].update({"issue_bound_ms": round(issue_ms, 2), "issue_bound_frac": round(issue_ms / kernel_ms, 4) if kernel_ms > 0 else None,
-                                    "issue_bound_model": "%d samples x %.2f coded symbols x %.1f VALU instructions x %.1f cycles / %.2f GHz, one coding wave per SIMD"
+                                    "issue_bound_model": "%d samples x %.2f coded symbols x %.1f instructions of the coding wave x %.1f cycles / %.2f GHz, one coding wave per SIMD"
                                                          % (T, sym, ISSUE_INSTR_PER_SYMBOL, ISSUE_CYCLES_PER_INSTR, SHADER_CLOCK_HZ / 1e9)})
             if env.pool is not None:
                 res["cpu_all_cores"] = cpu_all_cores(env.pool, env.ncores, xs)
