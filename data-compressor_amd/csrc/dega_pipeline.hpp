@@ -112,7 +112,7 @@ static void copy_streaming(uint8_t *dst, const uint8_t *src, size_t n)
 
 struct CopyPool
 {
-  static constexpr int N = 8;
+  static constexpr int N = 8; // (measured again in round 3 with 12 and 16 threads on a 16-core share: no difference -- the ring is not the limit)
   std::thread th[N];
   std::mutex m;
   std::condition_variable cv_work, cv_done;
