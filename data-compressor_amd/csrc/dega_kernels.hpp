@@ -1364,10 +1364,10 @@ DG_DEV void decode_parsing_wave(const DecodeArgs &a, uint32_t *pair_lds, uint32_
         bool more = false;
         auto take = [&]() {
           uint32_t sample;
-          const bool took = sp.template take_short<NARROW>(t_lane < t_limit, sample);
-          sring[(took ? (uint32_t)(t_lane % SRING) : SRING) * 64u] = sample;
-          t_lane += took ? 1u : 0u;
-          return took;
+          const uint32_t okm = sp.template take_short_lean<NARROW>(t_lane < t_limit, sample);
+          sring[select32(okm, t_lane % SRING, SRING) * 64u] = sample; // (a lane that took nothing writes to the spare slot)
+          t_lane -= okm;
+          return okm != 0u;
         };
 #pragma unroll
         for (uint32_t k = 0; k < DG_DEC_TAKES; k++)

@@ -1203,11 +1203,14 @@ struct BacDecoder
       {
         DG_MATERIALISE(out); // (left alone hipcc gathers the 32 symbols' bits and their D's at the end of the word: 60 live registers)
         DG_MATERIALISE(eof);
-        bad |= (off - off_group > 32u || off > 95u) ? 1u : 0u;
+        // all in vector arithmetic: masks made in scalar registers (compare, s_and, v_cndmask) put a VALU -> SALU -> VALU
+        // round trip into the word path four times per word.  `bad` collects sign bits: more than 32 bits in this group of
+        // eight symbols, or more than the four staged words hold.
+        bad |= (32u - (off - off_group)) | (95u - off);
         off_group = off;
-        const uint32_t o = off & 31u;
-        const uint32_t lo = off < 32u ? w0 : (off < 64u ? w1 : w2), hi = off < 32u ? w1 : (off < 64u ? w2 : w3);
-        ahead = o ? (lo << o) | (hi >> (32u - o)) : lo;
+        const uint32_t m32 = (uint32_t)((int32_t)(31u - off) >> 31), m64 = (uint32_t)((int32_t)(63u - off) >> 31); // off >= 32, off >= 64
+        const uint32_t lo = select32(m64, w2, select32(m32, w1, w0)), hi = select32(m64, w3, select32(m32, w2, w1));
+        ahead = (uint32_t)(((((uint64_t)lo << 32) | hi) << (off & 31u)) >> 32);
       }
     }
     bits_out = GENERAL ? out : (out ^ mm) & active;
@@ -1216,7 +1219,7 @@ struct BacDecoder
       mps = mm & 1u;
     else if (ADAPTIVE)
       tot += MASKED ? part_hi - part_lo + 1u : 32u;
-    return (int32_t)eof >= 0 && bad == 0;
+    return (int32_t)(eof | bad) >= 0;
   }
 };
 
@@ -1315,6 +1318,31 @@ struct SegParser
     win <<= m;
     cnt -= m;
     return ok;
+  }
+
+  // The same for the parsing wave's steady pass, in as few instructions as it takes (arithmetic masks instead of
+  // compares and selects; the parser stands between two codewords: need == zeros == 0).  `room`: the lane may produce a
+  // sample now.  Returns all ones when a codeword was taken (then `sample` is its value), else zero and nothing changed.
+  template <bool NARROW = false>
+  DG_DEV uint32_t take_short_lean(bool room, uint32_t &sample)
+  {
+    const uint32_t top = (uint32_t)(win >> 32);
+    const uint32_t p2 = 2u * clz32(top | 0x8000u);      // twice the prefix length; 32 = no short codeword here
+    // the codeword has p2 + 1 bits: whole iff p2 < cnt; short iff p2 <= 30 (narrow values: p <= pmax)
+    const uint32_t most = NARROW ? 2u * pmax + 1u : 31u;
+    const uint32_t lim = room ? (cnt < most ? cnt : most) : 0u;
+    const uint32_t okm = (uint32_t)((int32_t)(p2 - lim) >> 31); // all ones iff p2 < lim (both below 2^31)
+    const uint32_t w = top >> ((31u - p2) & 31u);          // code_number + 1 (junk when not ok: masked below)
+    const uint32_t sgn = 0u - (w & 1u);                  // odd w = even code number = negative (seg.c:77-78)
+    uint32_t d = ((w >> 1) ^ sgn) - sgn;
+    if (NARROW)
+      d = (uint32_t)((int32_t)(d << vshift) >> vshift);
+    const uint32_t m = (p2 | 1u) & okm;
+    last += d & okm;
+    sample = NARROW ? last & vmask : last;
+    win <<= m;
+    cnt -= m;
+    return okm;
   }
 
   // Tries to parse one codeword.  Returns 1 and the sample if a complete codeword was available, 0 if more bits are

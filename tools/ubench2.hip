@@ -154,6 +154,14 @@ K64_BOTH(lshr64, F64S, "v_lshrrev_b64")
 K64_BOTH(lshl_add64, F64A, "v_lshl_add_u64")
 K64_BOTH(mad64, FMAD64, "v_mad_u64_u32")
 K64_BOTH(mqsad, FQSAD, "v_mqsad_pk_u16_u8")
+// ---- selects by a lane mask in an SGPR pair: where the mask comes from ----
+#define FCMPCND(op, r) "v_cmp_lt_u32 vcc, %" #r ", %8\n\tv_cndmask_b32 %" #r ", %" #r ", %9, vcc\n\t"
+#define FCMPSCND(op, r) "v_cmp_lt_u32 vcc, %" #r ", %8\n\ts_and_b64 vcc, vcc, exec\n\tv_cndmask_b32 %" #r ", %" #r ", %9, vcc\n\t"
+#define FCNDS(op, r) "v_cndmask_b32 %" #r ", %" #r ", %9, s[4:5]\n\t"
+#define FBITOP(op, r) "v_bitop3_b32 %" #r ", %" #r ", %8, %9 bitop3:0x69\n\t"
+K_BOTH(cmp_cnd, FCMPCND, "")
+K_BOTH(cnd_sgpr, FCNDS, "")
+K_BOTH(bitop3, FBITOP, "")
 // ---- mixed streams in one wave ----
 KERN(mix_add_bfi, BODY32, R8(MIX8(F2, "v_add_u32", F3, "v_bfi_b32")), R8(MIX8(F2, "v_add_u32", F3, "v_bfi_b32")))
 KERN(mix_add_mulhi, BODY32, R8(MIX8(F2, "v_add_u32", F2, "v_mul_hi_u32")), R8(MIX8(F2, "v_add_u32", F2, "v_mul_hi_u32")))
@@ -198,6 +206,8 @@ int main(int argc, char **argv)
       T2("v_sub_u32_sdwa", sub_sdwa), T2("v_mov_b32_dpp quad_perm", mov_dpp), T2("v_add_u32_dpp row_shr", add_dpp),
       T2("v_pk_add_u16", pk_add16), T2("v_pk_lshlrev_b16", pk_lshl16), T2("v_pk_mul_lo_u16", pk_mul16),
       T2("v_lshlrev_b64", lshl64), T2("v_lshrrev_b64", lshr64), T2("v_lshl_add_u64", lshl_add64), T2("v_mad_u64_u32", mad64), T2("v_mqsad_pk_u16_u8", mqsad),
+      T2("v_cmp + v_cndmask vcc (2 instr)", cmp_cnd), T2("v_cndmask_b32 mask in s[4:5]", cnd_sgpr),
+      T2("v_bitop3_b32", bitop3),
       {"mix add/bfi ind", mix_add_bfi, 0}, {"mix add/mul_hi ind", mix_add_mulhi, 0}, {"mix add/xor ind", mix_add_xor, 0}, {"mix add/lshl ind", mix_add_lshl, 0},
   };
   std::vector<Test> pairs = {
@@ -212,6 +222,8 @@ int main(int argc, char **argv)
   printf("%-34s %12s %12s %12s\n", "stream", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
   for (auto &t : tests)
   {
+    if (argc > 1 && strstr(t.name, argv[1]) == NULL) // tools/ubench2 <substring>: only the streams whose name holds it
+      continue;
     CHECK(hipFuncSetAttribute((const void *)t.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double res[3];
     for (int m = 0; m < 3; m++)
