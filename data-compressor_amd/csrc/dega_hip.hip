@@ -280,8 +280,12 @@ static int check_job_shape(dega_hip_ctx *ctx, const Shape &j, size_t cap)
 template <bool AD, bool NARROW, bool F32>
 static void encode_launch(size_t C, hipStream_t s, const EncodeArgs &a)
 {
-  hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_RAW, ENC_ORING, false, F32>), dim3((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS)),
-                     dim3(ENC_BLOCK), 0, s, a);
+  const dim3 grid((unsigned)((C + ENC_CHANNELS - 1) / ENC_CHANNELS));
+  // short channels (and enough of them to fill the chip twice): half the table, small rings, two workgroups per CU
+  if (AD && a.T <= ENC_SHORT_T && a.seg_state == nullptr && C > 65536)
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, 4, 16, 8, 16, false, F32, ENC_PAIRS, ENC_SHORT_TABLE>), grid, dim3(ENC_BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL((dega_encode_kernel<AD, NARROW, ENC_ROWS, ENC_RING, ENC_RAW, ENC_ORING, false, F32>), grid, dim3(ENC_BLOCK), 0, s, a);
 }
 
 // `batch_C`: the channel count the workgroup shape is chosen by (the whole batch's when this launch is one chunk of it)

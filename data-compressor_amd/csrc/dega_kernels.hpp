@@ -778,18 +778,24 @@ DG_DEV void encode_coding_wave(const EncodeArgs &a, const uint32_t *tab, const u
 // magics: 4 groups = one coding wave per SIMD.  Batches of more than 64 Ki channels simply have more workgroups than the
 // chip holds at once (a workgroup takes a CU's LDS): measured, that beats packing two coding waves onto a SIMD with
 // smaller rings and one helper each (119 against 81 Gsamples/s on 128 Ki channels x 8 640).
+// TABW: division magics kept in LDS.  Channels of at most ENC_SHORT_T samples never count beyond 8 192 (cum[0] starts at 3
+// and grows by one per symbol, at most 65 symbols per sample): half the table and the small rings <.., 4, 16, 8, 16, ..>
+// leave room for TWO workgroups per CU -- two coding waves per SIMD, which cover for each other and get more instructions
+// per cycle out of it (BASELINE config 3: 1 Mi channels x 96 samples).
+constexpr uint32_t ENC_SHORT_TABLE = 8192;
+constexpr size_t ENC_SHORT_T = (ENC_SHORT_TABLE - 70) / 65; // 124
 template <bool ADAPTIVE, bool NARROW = false, uint32_t ROWS = ENC_ROWS, uint32_t RING = ENC_RING, uint32_t RAW = ENC_RAW, uint32_t ORING = ENC_ORING, bool W64 = false,
-          bool F32IN = false, uint32_t GROUPS = ENC_PAIRS>
+          bool F32IN = false, uint32_t GROUPS = ENC_PAIRS, uint32_t TABW = DIV_TABLE_SIZE>
 __global__ void __launch_bounds__(GROUPS * 192) dega_encode_kernel(const EncodeArgs a)
 {
   constexpr uint32_t LDS_ROWS = (W64 && !F32IN) ? 2 * ROWS : ROWS;
   // One LDS array for everything (with the LDS-DMA destination in an object of its own hipcc guards every other LDS
   // access with a vmcnt(0) wait):  division magics (64 KiB) | per group: seg-bit ring, raw ring, staging ring, input rows,
   // the three published rows
-  constexpr uint32_t TAB_WORDS = ADAPTIVE ? DIV_TABLE_SIZE : 4;
+  constexpr uint32_t TAB_WORDS = ADAPTIVE ? TABW : 4;
   constexpr uint32_t PER_GROUP = (RING + RAW + ORING + LDS_ROWS + 3) * 64;
   __shared__ __attribute__((aligned(16))) uint32_t lds[TAB_WORDS + GROUPS * PER_GROUP];
-  static_assert(sizeof(lds) <= 160 * 1024, "LDS budget of a CU");
+  static_assert(sizeof(lds) <= (TABW < DIV_TABLE_SIZE ? 80 : 160) * 1024, "LDS budget of a CU (half of it for the short-channel shape)");
   uint32_t *const tab = lds;
 
   const uint32_t lane = threadIdx.x & 63u;

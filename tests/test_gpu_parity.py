@@ -302,6 +302,27 @@ def test_cfg3_short_series_high_batch(ctx):
     assert_streams_equal(out[selt].cpu().numpy(), bits[selt].cpu().numpy().astype(np.uint64), np.zeros(len(sel), dtype=np.int32), *want, tag="cfg3")
 
 
+def test_short_channel_shape_at_its_longest_and_widest(ctx):
+    """The two-workgroups-per-CU encode shape (half the division table in LDS) is taken for more than 64 Ki channels of at
+    most 124 samples: at exactly 124 samples of 31-bit noise (the most symbols a sample can cost) a channel counts up to
+    the last table entry that shape holds; 125 samples take the ordinary shape.  Sampled channels byte for byte vs the oracle."""
+    import torch
+    Cn = 65536 + 320
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for T in (124, 125):
+        x = torch.randint(0, 2**31, (T, Cn), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)  # (diff.c:15-18: samples are read unsigned and a difference must fit int32)
+        cap = 4 * ((T * 12 + 67) // 4)
+        out, bits, err = ctx.encode(x, adaptive=1, cap=cap)
+        y, derr = ctx.decode(out, bits, T, adaptive=1)
+        torch.cuda.synchronize()
+        assert int((err != 0).sum()) == 0 and int((derr != 0).sum()) == 0
+        assert bool((y == x).all())
+        sel = np.concatenate([np.arange(0, Cn, 997), np.arange(Cn - 70, Cn)])
+        selt = torch.from_numpy(sel).cuda()
+        want = orc.encode_batch_tc(x[:, selt].cpu().numpy(), 1, cap=cap)
+        assert_streams_equal(out[selt].cpu().numpy(), bits[selt].cpu().numpy().astype(np.uint64), np.zeros(len(sel), dtype=np.int32), *want, tag="short T=%d" % T)
+
+
 def test_cfg5_style_streamed_batches(ctx):
     """configs[4] in miniature: a channel population larger than one resident batch is streamed through the device in
     batches (here 4 x 32 Ki channels x 1500 samples, generated per batch from the channel ids), encode + decode per
