@@ -187,6 +187,10 @@ DG_DEV void wait_vector_memory()
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+DG_DEV void wait_lds() // every LDS read of this wave so far has returned
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 #else
 inline void dma_x4_to_lds(const int32_t *src, uint32_t *lds_base, uint32_t lane)
 {
@@ -198,6 +202,7 @@ inline void dma_row_to_lds(const int32_t *src, uint32_t *lds_row, uint32_t lane)
   lds_row[lane] = (uint32_t)*src;
 }
 inline void wait_vector_memory() {}
+inline void wait_lds() {}
 #endif
 
 // ---- two waves of one workgroup talking through LDS (the paired-wave kernels: one wave codes, its partner parses) -----

@@ -748,7 +748,10 @@ __global__ void __launch_bounds__(LZ_ENC_THREADS) lzmh_encode_kernel(const LzmhE
 // restated literally, including what it does at the end of a stream: it keeps decoding while the register holds a set
 // bit (:571) and stops silently on an unknown list code (:447-449).  List entries that were never written read as symbol
 // 0 here (the reference reads uninitialised stack there).
-constexpr uint32_t LZD_HIST_DW = LZ_HISTORY / 4;
+// The history ring is kept TWICE the reference's 128 bytes (:396): the writing wave appends up to 8 bytes a pass as whole
+// dwords, zeros behind the last byte included, and those zeros land on ring bytes 245..256 back -- never read.
+constexpr uint32_t LZD_RING_BYTES = 2 * LZ_HISTORY;
+constexpr uint32_t LZD_HIST_DW = LZD_RING_BYTES / 4;
 constexpr uint32_t LZD_OFF_HIST = 0, LZD_OFF_SYM = LZD_OFF_HIST + LZD_HIST_DW * LZ_BLOCK, LZD_OFF_CNT = LZD_OFF_SYM + LZ_SYM_DW * LZ_BLOCK,
                    LZD_LDS_DW = LZD_OFF_CNT + LZ_CNT_DW * LZ_BLOCK;
 
@@ -771,10 +774,10 @@ struct LzmhDecodeArgs
 //   reader publishes: tokens written (mod 2^16) | no more will come << 24
 //   writer publishes: tokens taken (mod 2^16)   | the lane wants no more (output full) << 16
 constexpr uint32_t LZD_TOK_RING = 8;
-constexpr uint32_t LZD_OFF_TOK = LZD_LDS_DW, LZD_OFF_PUB = LZD_OFF_TOK + LZD_TOK_RING * LZ_BLOCK, LZD_PAIR_LDS_DW = LZD_OFF_PUB + 2 * LZ_BLOCK;
+constexpr uint32_t LZD_OFF_TOK = LZD_LDS_DW, LZD_OFF_PUB = LZD_OFF_TOK + LZD_TOK_RING * LZ_BLOCK, LZD_OFF_PEND = LZD_OFF_PUB + 2 * LZ_BLOCK,
+                   LZD_PAIR_LDS_DW = LZD_OFF_PEND + LZ_BLOCK;
 constexpr uint32_t LZD_THREADS = 2 * LZ_BLOCK; // LZ_BLOCK channels per workgroup, two waves per 64 of them
 
-#define LZ_HIST8(b) hist8[((b) >> 2) * (4u * LZ_BLOCK) + ((b) & 3u)]
 #define LZ_SYM8(i) sym8[((i) >> 2) * (4u * LZ_BLOCK) + ((i) & 3u)]
 #define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
 
@@ -795,12 +798,18 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
 
   uint64_t ip = 0;            // next input bit
   uint32_t wi = 0;            // index of w0
-  uint32_t w0 = 0, w1 = 0, w2 = 0; // stream words wi, wi+1, wi+2 (w2 is the one in flight)
+  // stream words wi, wi+1, wi+2 in registers; word wi+3 is on its way into the lane's dword of an LDS row (LDS-DMA: no
+  // register waits for it) and is picked up at the lane's NEXT word step, a few passes on.  (Loaded into a register at the
+  // step that needs it, every pass in which any lane stepped -- nearly every pass -- ended with a wait for device memory.)
+  uint32_t *const pend_row = lds + LZD_OFF_PEND + (slot & ~63u); // (wave uniform)
+  const uint32_t *const pend = lds + LZD_OFF_PEND + slot;
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
   if (live && !bad)
   {
     w0 = bswap32(src[0]);
     w1 = bswap32(src[1 < last_word ? 1 : last_word]);
     w2 = bswap32(src[2 < last_word ? 2 : last_word]);
+    dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (3 < last_word ? 3 : last_word)), pend_row, slot & 63u);
   }
   uint32_t code_sym = 0;
   int32_t code_length = 0;
@@ -840,8 +849,11 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
         wi = nwi;
         w0 = w1;
         w1 = w2;
-        const uint32_t idx = wi + 2u;
-        w2 = bswap32(src[idx < last_word ? idx : last_word]);
+        wait_vector_memory(); // (the word asked for at the last step: long there)
+        w2 = bswap32(peer_load(pend));
+        wait_lds(); // it is out of the row before the next one can land
+        const uint32_t idx = wi + 3u;
+        dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (idx < last_word ? idx : last_word)), pend_row, slot & 63u);
       }
     }
     if ((code_sym & 0x80000000u) != 0) // list code
@@ -1027,13 +1039,17 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
     peer_store(pub_mine, (wr & 0xFFFFu) | ((finished || stop) ? LZ_PUB_DONE : 0u));
   }
   peer_store(pub_mine, (wr & 0xFFFFu) | LZ_PUB_DONE);
+  wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
 }
 
 // ---- the writing wave ------------------------------------------------------------------------------------------------
+// One pass appends up to 8 bytes per lane -- a literal, or the next 8 of a match (a longer match keeps its lane for
+// further passes) -- in one round of LDS reads: the 8 bytes `offset` back as three ring dwords, a match that overlaps its
+// own output (offset < 8) as its period repeated; then the ring and the 8-byte output accumulator each take them as one
+// shifted value.  (Byte by byte the copy was a chain of dependent LDS round trips, 15 instructions a byte.)
 DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
 {
-  uint8_t *const hist8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_HIST + slot);
-  const uint32_t *const histd = lds + LZD_OFF_HIST + slot; // dword d of the ring: histd[d * LZ_BLOCK]
+  uint32_t *const histd = lds + LZD_OFF_HIST + slot; // dword d of the ring: histd[d * LZ_BLOCK]
   const uint32_t *const tok = lds + LZD_OFF_TOK + slot;
   const uint32_t *const pub_peer = lds + LZD_OFF_PUB + slot;
   uint32_t *const pub_mine = lds + LZD_OFF_PUB + LZ_BLOCK + slot;
@@ -1041,73 +1057,107 @@ DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
   const uint64_t nbits = live ? a.in_bits[c] : 0;
   uint8_t *const dst = a.out + (live ? c : 0) * a.stride;
   int32_t err = (nbits > 8ull * a.cap || a.cap < 4) ? ERR_INVALID_VALUE : OK;
-  uint32_t hp = 0;
-  uint64_t obuf = 0;
+  uint32_t hp = 0;      // ring position of the next byte
+  uint32_t hcur = 0;    // the ring dword hp lies in: its bytes below hp, zeros above
+  uint64_t obuf = 0;    // output bytes not stored yet, first byte lowest
   uint32_t nob = 0;
   uint64_t olen = 0;
   uint32_t rd = 0;
+  uint32_t rem = 0, offset = 1; // the match being copied: bytes left, distance
   uint32_t peer = peer_load(pub_peer); // (one pass old when it is used: see the DEGA coding waves)
   wave_priority<DG_LZ_WRITE_PRIO>();
 
-  // one decoded byte: history ring + 8-byte output accumulator
-#define LZ_EMIT(b)                                                  \
-  do                                                                \
-  {                                                                 \
-    const uint32_t b_ = (b);                                        \
-    LZ_HIST8(hp) = (uint8_t)b_;                                     \
-    hp = (hp + 1u) & (LZ_HISTORY - 1u);                             \
-    obuf |= (uint64_t)b_ << (8u * nob);                             \
-    if (++nob == 8u)                                                \
-    {                                                               \
-      if (olen + 8u > a.stride)                                     \
-        err = ERR_MEMORY;                                           \
-      else                                                          \
-        *reinterpret_cast<uint64_t *>(dst + olen) = obuf;           \
-      olen += 8;                                                    \
-      obuf = 0;                                                     \
-      nob = 0;                                                      \
-    }                                                               \
-  } while (0)
-
   for (;;)
   {
-    const bool has = live && ((peer - rd) & 0xFFFFu) != 0u && err == OK;
+    const bool copying_on = rem > 0u;
+    const bool has = live && !copying_on && ((peer - rd) & 0xFFFFu) != 0u && err == OK;
     const bool peer_done = (peer & LZ_PUB_DONE) != 0u;
     const uint32_t token = tok[(rd % LZD_TOK_RING) * LZ_BLOCK];
     peer = peer_load(pub_peer);
-    if (!wave_any(has))
+    if (!wave_any(has || copying_on))
     {
       if (wave_all(!live || peer_done || err != OK))
         break;
       wave_sleep<DG_LZ_WRITE_SLEEP>();
       continue;
     }
+    const bool lit = has && token < 0x100u;
     if (has)
     {
       rd++;
-      if (token < 0x100u)
-        LZ_EMIT(token);
-      else
+      if (!lit)
       {
-        const uint32_t offset = token & 0xFFu, length = token >> 8;
-        uint32_t k = 0;
-        // four bytes per round while the source lies at least four bytes back (none of them is written in this round):
-        // one LDS latency for four bytes instead of four -- the copy is a chain of dependent LDS round trips
-        if (offset >= 4u)
-          for (; k + 4u <= length && err == OK; k += 4u)
-          {
-            const uint32_t from = (hp - offset) & (LZ_HISTORY - 1u);
-            const uint32_t d0 = histd[(from >> 2) * LZ_BLOCK], d1 = histd[(((from >> 2) + 1u) & (LZ_HISTORY / 4u - 1u)) * LZ_BLOCK];
-            const uint32_t four = lz_alignbyte(d1, d0, from & 3u);
-            LZ_EMIT(four & 0xFFu);
-            LZ_EMIT((four >> 8) & 0xFFu);
-            LZ_EMIT((four >> 16) & 0xFFu);
-            LZ_EMIT(four >> 24);
-          }
-        for (; k < length && err == OK; k++)
+        // (offset 0 -- only a damaged stream has it, from a recent-offset entry never set -- reads the reference's
+        // 128-byte ring at the write position itself: the byte 128 back)
+        offset = (token & 0xFFu) != 0u ? (token & 0xFFu) : LZ_HISTORY;
+        rem = token >> 8;
+      }
+    }
+    const bool copying = rem > 0u;
+    uint32_t vlo = token & 0xFFu, vhi = 0, n = 1;
+    if (wave_any(copying))
+    {
+      const uint32_t from = (hp - offset) & (LZD_RING_BYTES - 1u);
+      const uint32_t fd = from >> 2, fs = from & 3u;
+      const uint32_t w0 = histd[fd * LZ_BLOCK], w1 = histd[((fd + 1u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK],
+                     w2 = histd[((fd + 2u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK];
+      uint64_t m = ((uint64_t)lz_alignbyte(w2, w1, fs) << 32) | lz_alignbyte(w1, w0, fs); // the 8 bytes `offset` back
+      if (wave_any(copying && offset < 8u))
+      {
+        // the bytes from hp on are not written yet: a period of `offset` bytes, repeated (1 -> 2 -> 4 -> 8 periods)
+        const uint32_t pb = 8u * (offset < 8u ? offset : 8u);
+        uint64_t r = pb < 64u ? m & ((1ull << pb) - 1ull) : m;
+        r |= pb < 64u ? r << pb : 0ull;
+        r |= 2u * pb < 64u ? r << (2u * pb) : 0ull;
+        r |= 4u * pb < 64u ? r << (4u * pb) : 0ull;
+        m = r;
+      }
+      const uint32_t nm = rem < 8u ? rem : 8u;
+      m = nm < 8u ? m & ((1ull << (8u * nm)) - 1ull) : m;
+      vlo = copying ? (uint32_t)m : vlo;
+      vhi = copying ? (uint32_t)(m >> 32) : vhi;
+      n = copying ? nm : n;
+    }
+    if (lit || copying)
+    {
+      const uint64_t v = ((uint64_t)vhi << 32) | vlo;
+      rem -= copying ? n : 0u;
+      // ---- the ring: the 96 bits hcur | v << (8 * (hp & 3)) as three dwords ----
+      {
+        const uint32_t sh = 8u * (hp & 3u);
+        const uint64_t lo64 = v << sh;
+        const uint32_t x0 = hcur | (uint32_t)lo64, x1 = (uint32_t)(lo64 >> 32), x2 = (uint32_t)((v >> 32) >> (32u - sh));
+        const uint32_t d0 = hp >> 2;
+        histd[d0 * LZ_BLOCK] = x0;
+        histd[((d0 + 1u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK] = x1;
+        histd[((d0 + 2u) & (LZD_HIST_DW - 1u)) * LZ_BLOCK] = x2;
+        const uint32_t at = ((hp & 3u) + n) >> 2; // the dword of the three that the new hp lies in (0..2)
+        hcur = at == 0u ? x0 : at == 1u ? x1 : x2;
+        hp = (hp + n) & (LZD_RING_BYTES - 1u);
+      }
+      // ---- the output: the 128 bits obuf | v << (8 * nob); 8 bytes stored when there are that many ----
+      {
+        const uint32_t osh = 8u * nob;
+        const uint64_t ylo = obuf | (v << osh);
+        const uint64_t yhi = osh != 0u ? v >> (64u - osh) : 0ull;
+        const uint32_t tot = nob + n;
+        if (tot >= 8u)
         {
-          const uint32_t sym = LZ_HIST8((hp - offset) & (LZ_HISTORY - 1u));
-          LZ_EMIT(sym);
+          if (olen + 8u > a.stride)
+          {
+            err = ERR_MEMORY;
+            rem = 0;
+          }
+          else
+            *reinterpret_cast<uint64_t *>(dst + olen) = ylo;
+          olen += 8;
+          obuf = yhi;
+          nob = tot - 8u;
+        }
+        else
+        {
+          obuf = ylo;
+          nob = tot;
         }
       }
     }
@@ -1128,7 +1178,6 @@ DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
     a.out_len[c] = err == OK ? olen : 0;
     a.err[c] = err;
   }
-#undef LZ_EMIT
 }
 
 __global__ void __launch_bounds__(LZD_THREADS) lzmh_decode_kernel(const LzmhDecodeArgs a)
@@ -1151,7 +1200,6 @@ __global__ void __launch_bounds__(LZD_THREADS) lzmh_decode_kernel(const LzmhDeco
   else
     lzmh_reading_wave(a, lds, slot, c, live);
 }
-#undef LZ_HIST8
 #undef LZ_SYM8
 #undef LZ_CNT
 
