@@ -160,8 +160,9 @@ DG_DEV uint32_t wave_max_u32(uint32_t v)
 }
 #endif
 
-#if defined(DEGA_DIAG) && (DEGA_DIAG & 32) && !defined(DEGA_SIM)
-// diagnostic build: per-wave cycle totals per section of the encode loop (s_memtime), dumped over out_bits[] / err[]
+#if defined(DEGA_DIAG) && (DEGA_DIAG & (32 | 256)) && !defined(DEGA_SIM)
+// diagnostic build: per-wave cycle totals per section of a loop (s_memtime): 32 = the LZMH searching wave, dumped over
+// out_bits[]; 256 = the LZMH reading wave, dumped over out_len[]
 #define DG_STAMP_DECL uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define DG_STAMP(k) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_sum[k] += now_ - stamp_t0; stamp_cnt[k]++; stamp_t0 = now_; } while (0)
 #else

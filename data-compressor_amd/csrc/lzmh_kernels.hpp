@@ -210,7 +210,7 @@ constexpr uint32_t LZ_PUB_DONE = 1u << 24, LZ_PUB_FINAL = 1u << 16;
 #define DG_LZ_CODE_PRIO 0
 #endif
 #ifndef DG_LZ_WRITE_PRIO
-#define DG_LZ_WRITE_PRIO 1 // (measured: the writing wave above the reading wave, 14.9 -> 13.5 ms on the probe batch)
+#define DG_LZ_WRITE_PRIO 0 // (the reading wave is the chain now: with the writing wave above it 10.6 ms on the probe batch, level 8.85)
 #endif
 #ifndef DG_LZ_SEARCH_SLEEP // how long a wave with nothing to do sleeps (units of 64 cycles)
 #define DG_LZ_SEARCH_SLEEP 1
@@ -782,7 +782,7 @@ constexpr uint32_t LZD_THREADS = 2 * LZ_BLOCK; // LZ_BLOCK channels per workgrou
 #define LZ_CNT(i) cnt16[((i) >> 1) * (2u * LZ_BLOCK) + ((i) & 1u)]
 
 // ---- the reading wave ------------------------------------------------------------------------------------------------
-DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, size_t c, bool live)
+DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t slot, uint32_t slot0, size_t c, bool live) // slot0: the wave's first
 {
   uint8_t *const sym8 = reinterpret_cast<uint8_t *>(lds + LZD_OFF_SYM + slot);
   uint16_t *const cnt16 = reinterpret_cast<uint16_t *>(lds + LZD_OFF_CNT + slot);
@@ -801,7 +801,7 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
   // stream words wi, wi+1, wi+2 in registers; word wi+3 is on its way into the lane's dword of an LDS row (LDS-DMA: no
   // register waits for it) and is picked up at the lane's NEXT word step, a few passes on.  (Loaded into a register at the
   // step that needs it, every pass in which any lane stepped -- nearly every pass -- ended with a wait for device memory.)
-  uint32_t *const pend_row = lds + LZD_OFF_PEND + (slot & ~63u); // (wave uniform)
+  uint32_t *const pend_row = lds + LZD_OFF_PEND + slot0; // (wave uniform; lane l's dword is pend_row[l])
   const uint32_t *const pend = lds + LZD_OFF_PEND + slot;
   uint32_t w0 = 0, w1 = 0, w2 = 0;
   if (live && !bad)
@@ -809,7 +809,7 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
     w0 = bswap32(src[0]);
     w1 = bswap32(src[1 < last_word ? 1 : last_word]);
     w2 = bswap32(src[2 < last_word ? 2 : last_word]);
-    dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (3 < last_word ? 3 : last_word)), pend_row, slot & 63u);
+    dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (3 < last_word ? 3 : last_word)), pend_row, slot - slot0);
   }
   uint32_t code_sym = 0;
   int32_t code_length = 0;
@@ -819,7 +819,10 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
   bool finished = !live || bad;
   bool stop = false;   // the writer wants no more of this channel
   wave_priority<DG_LZ_READ_PRIO>();
+  DG_STAMP_DECL;
 
+  uint32_t mail = 0;       // the lane's dword of the row as read at the top of this pass
+  bool mail_fresh = false; // ... and not used yet
   // one pass of the reference's loop body up to the point where it writes (lzmh.c:410-560): the next token, if any
   auto next_token = [&](uint32_t &token, bool &emitted) {
     // ---- top the register up to 25 bits (lzmh.c:410-415); bits shifted in while code_length <= 0 fall off ----
@@ -849,31 +852,63 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
         wi = nwi;
         w0 = w1;
         w1 = w2;
-        wait_vector_memory(); // (the word asked for at the last step: long there)
-        w2 = bswap32(peer_load(pend));
-        wait_lds(); // it is out of the row before the next one can land
+        uint32_t raw = mail; // (read at the top of the pass, with the partner's word: no LDS round trip of its own)
+        if (!mail_fresh)     // a second word step in one pass (bits that fall off a damaged stream's register): rare
+        {
+          wait_vector_memory();
+          raw = peer_load(pend);
+          wait_lds(); // it is out of the row before the next one can land
+        }
+        mail_fresh = false;
+        w2 = bswap32(raw);
         const uint32_t idx = wi + 3u;
-        dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (idx < last_word ? idx : last_word)), pend_row, slot & 63u);
+        dma_row_to_lds(reinterpret_cast<const int32_t *>(src + (idx < last_word ? idx : last_word)), pend_row, slot - slot0);
       }
     }
-    if ((code_sym & 0x80000000u) != 0) // list code
+    DG_STAMP(1);
+    // The three kinds of code -- 1... a list position, 00 + byte, 01 a match -- without a branch per kind where that can be
+    // helped: the lanes of a wave are spread over all of them.  The list entry's LDS reads go out first (every lane, a
+    // harmless address for those with another kind), the match fields are worked out while they are on their way.
+    const bool is_list = (code_sym & 0x80000000u) != 0;
+    const bool is_match = !is_list && (code_sym & 0x40000000u) != 0;
+    uint32_t llen;
+    uint32_t li = lz_list_position(code_sym >> 24, llen);
+    // (a code cut off by the end of the stream matches no table entry, lzmh.c:423: the reference returns NO_ERROR there)
+    const bool unknown = is_list && code_length < (int32_t)llen;
+    li = is_list ? li : 0u;
+    // the entry, its count and the two entries in front of it in one round of LDS reads (the bubble-up rarely goes further)
+    const uint32_t lp1 = li > 0 ? li - 1u : 0u, lp2 = li > 1 ? li - 2u : 0u;
+    const uint32_t lsym = LZ_SYM8(li), c0 = LZ_CNT(li), c1 = LZ_CNT(lp1), c2 = LZ_CNT(lp2), s1 = LZ_SYM8(lp1), s2 = LZ_SYM8(lp2);
+
+    // ---- a match (lzmh.c:487-553) ----
+    // the offset field after the two bits "01": 0 + 7 bits = a new offset | 10 | 110 | 1110 | 1111 = the most recent
+    // offset, the one before, ... (:489-531) -- the run of ones tells which
+    const uint32_t x = code_sym << 2;
+    const uint32_t ones = clz32(~x | 0x08000000u);                    // 0..4
+    const uint32_t used_o = ones == 0u ? 8u : (ones == 4u ? 4u : ones + 1u);
+    const uint32_t at = 8u * (ones == 0u ? 3u : ones - 1u);            // bit position of the entry that leaves its place
+    const uint32_t offset = ones == 0u ? ((x >> 24) & 0x7Fu) + 1u : (mru >> at) & 0xFFu;
+    // move to front: the entries in front of it move up one place, those behind stay (a new offset: the oldest drops out)
+    const uint32_t mru_m = (mru & (0xFFFFFF00u << at)) | ((mru & ((1u << at) - 1u)) << 8) | offset;
+    // the length field: 0 + 3 bits = 3..10 | 10 + 3 bits = 11..18 | 11 + 8 bits = 19..274 (:533-553)
+    const uint32_t y = x << used_o;
+    const uint32_t top = y >> 30;
+    const uint32_t length = top < 2u ? ((y >> 28) & 7u) + 3u : (top == 2u ? ((y >> 27) & 7u) + 11u : ((y >> 22) & 0xFFu) + 19u);
+    const uint32_t used_m = 2u + used_o + (top < 2u ? 4u : (top == 2u ? 5u : 10u));
+    mru = is_match ? mru_m : mru;
+
+    // ---- every kind: the bits it used, its token ----
+    const uint32_t used = is_list ? (unknown ? 0u : llen) : (is_match ? used_m : 10u);
+    const uint32_t raw_sym = (code_sym >> 22) & 0xFFu;
+    token = is_list ? lsym : (is_match ? (length << 8) | offset : raw_sym);
+    emitted = !unknown;
+    finished = finished || unknown;
+    code_length -= (int32_t)used;
+    code_sym <<= used;
+
+    if (is_list && !unknown) // the list entry moves towards the front past entries with a smaller count: only symbols move
     {
-      uint32_t len;
-      uint32_t i = lz_list_position(code_sym >> 24, len);
-      if (code_length < (int32_t)len)
-        i = LZ_TREE; // the code is cut off by the end of the stream: no table entry matches (lzmh.c:423)
-      if (i == LZ_TREE)
-      {
-        finished = true; // unknown code: the reference returns NO_ERROR here
-        return;
-      }
-      // the entry, its count and the two entries in front of it in one round of LDS reads (the bubble-up rarely goes further)
-      const uint32_t p1 = i > 0 ? i - 1u : 0u, p2 = i > 1 ? i - 2u : 0u;
-      const uint32_t sym = LZ_SYM8(i), c0 = LZ_CNT(i), c1 = LZ_CNT(p1), c2 = LZ_CNT(p2), s1 = LZ_SYM8(p1), s2 = LZ_SYM8(p2);
-      code_length -= (int32_t)len;
-      code_sym <<= len;
-      token = sym;
-      emitted = true;
+      uint32_t i = li;
       if (c0 < 65535u)
       {
         if (i > 0 && c0 + 1u > c1)
@@ -892,19 +927,15 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
           }
         }
         LZ_CNT(i) = (uint16_t)(c0 + 1u);
-        LZ_SYM8(i) = (uint8_t)sym;
+        LZ_SYM8(i) = (uint8_t)lsym;
         if (i == nvalid) // only a damaged stream names an entry that is not in use yet
           for (nvalid++; nvalid < LZ_LIST && LZ_CNT(nvalid) > 0; nvalid++)
             ;
       }
     }
-    else if ((code_sym & 0x40000000u) == 0) // 00 + byte
+    if (!is_list && !is_match) // 00 + byte
     {
-      const uint32_t sym = (code_sym >> 22) & 0xFFu;
-      code_length -= 10;
-      code_sym <<= 10;
-      token = sym;
-      emitted = true;
+      const uint32_t sym = raw_sym;
       // the reference walks the list until the symbol or the first unused entry (:463-465); here the symbol dwords are
       // searched byte-parallel in one round of LDS reads and the first unused entry is known (nvalid)
       uint32_t i = nvalid;
@@ -937,83 +968,14 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
         }
       }
     }
-    else // match
-    {
-      uint32_t offset, length;
-      code_length -= 2;
-      code_sym <<= 2;
-      if ((code_sym & 0x80000000u) == 0)
-      {
-        offset = ((code_sym >> 24) & 0x7Fu) + 1u;
-        code_length -= 8;
-        code_sym <<= 8;
-        mru = (mru << 8) | offset;
-      }
-      else
-      {
-        code_length -= 1;
-        code_sym <<= 1;
-        if ((code_sym & 0x80000000u) == 0)
-          offset = mru & 0xFFu;
-        else
-        {
-          code_length -= 1;
-          code_sym <<= 1;
-          if ((code_sym & 0x80000000u) == 0)
-          {
-            offset = (mru >> 8) & 0xFFu;
-            mru = (mru & 0xFFFF0000u) | ((mru & 0xFFu) << 8) | offset;
-          }
-          else
-          {
-            code_length -= 1;
-            code_sym <<= 1;
-            if ((code_sym & 0x80000000u) == 0)
-            {
-              offset = (mru >> 16) & 0xFFu;
-              mru = (mru & 0xFF000000u) | ((mru & 0xFFFFu) << 8) | offset;
-            }
-            else
-            {
-              offset = mru >> 24;
-              mru = (mru << 8) | offset;
-            }
-          }
-        }
-        code_length -= 1;
-        code_sym <<= 1;
-      }
-      if ((code_sym & 0x80000000u) == 0)
-      {
-        length = ((code_sym >> 28) & 7u) + 3u;
-        code_length -= 4;
-        code_sym <<= 4;
-      }
-      else
-      {
-        code_length -= 1;
-        code_sym <<= 1;
-        if ((code_sym & 0x80000000u) == 0)
-        {
-          length = ((code_sym >> 28) & 7u) + 11u;
-          code_length -= 4;
-          code_sym <<= 4;
-        }
-        else
-        {
-          length = ((code_sym >> 23) & 0xFFu) + 19u;
-          code_length -= 9;
-          code_sym <<= 9;
-        }
-      }
-      token = (length << 8) | offset;
-      emitted = true;
-    }
   };
 
   for (;;)
   {
+    wait_vector_memory(); // (the words asked for in the last pass: long there)
     const uint32_t peer = peer_load(pub_peer);
+    mail = peer_load(pend);
+    mail_fresh = true;
     stop = stop || (peer & LZ_PUB_FINAL) != 0u;
     const bool todo = !finished && !stop;
     if (!wave_any(todo))
@@ -1022,13 +984,16 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
     if (!wave_any(active))
     {
       wave_sleep<DG_LZ_READ_SLEEP>();
+      DG_STAMP(7);
       continue;
     }
+    DG_STAMP(0);
     if (active)
     {
       uint32_t token = 0;
       bool emitted = false;
       next_token(token, emitted);
+      DG_STAMP(2);
       if (emitted)
       {
         tok[(wr % LZD_TOK_RING) * LZ_BLOCK] = token;
@@ -1037,9 +1002,19 @@ DG_DEV void lzmh_reading_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
       finished = finished || !(ip < nbits || code_sym > 0); // the loop condition of lzmh.c:571 (its error half is the writer's)
     }
     peer_store(pub_mine, (wr & 0xFFFFu) | ((finished || stop) ? LZ_PUB_DONE : 0u));
+    DG_STAMP(3);
   }
   peer_store(pub_mine, (wr & 0xFFFFu) | LZ_PUB_DONE);
   wait_vector_memory(); // no DMA may still be writing to LDS when the workgroup's allocation is released
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 256) && !defined(DEGA_SIM)
+  if (live) // diagnostic build: the stamps of the first 16 lanes of every wave instead of the decoded lengths
+  {
+    if ((slot & 63u) < 8)
+      a.out_len[c] = stamp_sum[slot & 63u];
+    else if ((slot & 63u) < 16)
+      a.out_len[c] = stamp_cnt[(slot & 63u) - 8];
+  }
+#endif
 }
 
 // ---- the writing wave ------------------------------------------------------------------------------------------------
@@ -1175,11 +1150,17 @@ DG_DEV void lzmh_writing_wave(const LzmhDecodeArgs &a, uint32_t *lds, uint32_t s
         *reinterpret_cast<uint64_t *>(dst + olen) = obuf;
       olen += nob;
     }
-    a.out_len[c] = err == OK ? olen : 0;
+#if defined(DEGA_DIAG) && (DEGA_DIAG & 256) && !defined(DEGA_SIM)
+    if ((slot & 63u) >= 16) // (the reading wave dumps its stamps over the first 16)
+#endif
+      a.out_len[c] = err == OK ? olen : 0;
     a.err[c] = err;
   }
 }
 
+// (Tried: 32 channels per wave and twice the waves, two reading and two writing waves per SIMD, for up to 64 Ki
+// channels -- 15.4 ms against 11.1 on the probe batch: the reading wave's chain does not leave the gaps a second one
+// could use, the four waves only get in each other's way.)
 __global__ void __launch_bounds__(LZD_THREADS) lzmh_decode_kernel(const LzmhDecodeArgs a)
 {
   __shared__ uint32_t lds[LZD_PAIR_LDS_DW];
@@ -1198,7 +1179,7 @@ __global__ void __launch_bounds__(LZD_THREADS) lzmh_decode_kernel(const LzmhDeco
   if (writes)
     lzmh_writing_wave(a, lds, slot, c, live);
   else
-    lzmh_reading_wave(a, lds, slot, c, live);
+    lzmh_reading_wave(a, lds, slot, slot - lane, c, live);
 }
 #undef LZ_SYM8
 #undef LZ_CNT

@@ -46,6 +46,11 @@ back, blens, derr = ctx.lzmh_decode(out, bits, stride, out=back)
 torch.cuda.synchronize()
 ctx.profile(False)
 n, dms = ctx.profile_read(3)
+if "diag256" in dca.LIB_PATH:
+    b = blens.cpu().numpy().reshape(-1, 64)
+    names = ["loop_top", "top_up", "token", "publish", "-", "-", "-", "sleep"]
+    print("decode: kernel %.3f ms; reading wave" % dms, {names[k]: [int(b[:, k].mean()), int(b[:, 8 + k].mean())] for k in (0, 1, 2, 3, 7)}, "total", int(b[:, :8].sum(axis=1).mean()))
+    sys.exit(0)
 idx = torch.arange(stride, device="cuda")[None, :] < lens[:, None]
 ok = bool((blens == lens).all().item()) and bool(((back == text) | ~idx).all().item()) and int((derr != 0).sum().item()) == 0
 print("decode: kernel %.3f ms -> %.2f GB/s, round trip %s" % (dms, nbytes / dms / 1e6, "bit-exact" if ok else "MISMATCH"), flush=True)
