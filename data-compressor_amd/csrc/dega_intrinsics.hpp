@@ -73,6 +73,26 @@ DG_DEV uint32_t select32(uint32_t mask, uint32_t if_set, uint32_t if_clear) // m
 #endif
 }
 
+// Any function of three words bit by bit in one instruction (v_bitop3_b32, gfx950); the table is the function applied
+// to 0xF0, 0xCC, 0xAA.  hipcc finds these itself in plain expressions, but not across an inline-asm operand.
+DG_DEV uint32_t xor_then_or(uint32_t a, uint32_t b, uint32_t c) // (a ^ b) | c
+{
+#if defined(DEGA_SIM)
+  return (a ^ b) | c;
+#else
+  return __builtin_amdgcn_bitop3_b32(a, b, c, ((0xF0 ^ 0xCC) | 0xAA) & 0xFF);
+#endif
+}
+
+DG_DEV uint32_t andn_and(uint32_t a, uint32_t b, uint32_t c) // ~a & b & c
+{
+#if defined(DEGA_SIM)
+  return ~a & b & c;
+#else
+  return __builtin_amdgcn_bitop3_b32(a, b, c, (~0xF0 & 0xCC & 0xAA) & 0xFF);
+#endif
+}
+
 // Number of leading one bits of x, for x with bit 31 set and not all ones (v_ffbh_i32 counts the bits equal to the sign).
 DG_DEV uint32_t leading_ones(uint32_t x)
 {

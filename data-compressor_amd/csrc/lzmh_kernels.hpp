@@ -15,8 +15,9 @@
 // How a lane searches (the 128-offset scan is ~90% of the reference's time):
 //   phase 1  the lane's last 132 window bytes + the next 24 are read from LDS into registers (38 dwords, one latency),
 //            and a byte-parallel compare marks every position whose first three bytes equal the next three input bytes:
-//            per dword 2 v_alignbyte, 3 xor, or3, a zero-byte test and a multiply that gathers the four flags -- 11
-//            instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
+//            per dword 2 v_alignbyte, xor, two v_bitop3, a zero-byte test (add, v_bitop3) and a multiply that gathers the
+//            four flags -- 9
+//            (round 2: 11) instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
 //   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass of the wave's
 //            loop, and measured against the input bytes held in registers -- the first 8 bytes of all five, then the
 //            next 8 of the few that match those (all LDS reads of a round in flight together); `len > best` in that
@@ -88,7 +89,7 @@ DG_DEV uint32_t lz_shift_in_nibble(uint32_t acc, uint32_t m) // (acc >> 4) | (m 
 // flagged too when it is 0x01 (borrow) -- callers verify candidates
 DG_DEV uint32_t lz_zero_bytes_approx(uint32_t y)
 {
-  return select32(y, 0u, y - 0x01010101u) & 0x80808080u;
+  return andn_and(y, y - 0x01010101u, 0x80808080u);
 }
 
 DG_DEV uint32_t lz_zero_bytes_exact(uint32_t y)
@@ -339,6 +340,9 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
 #pragma unroll
       for (uint32_t j = 0; j < 38; j++)
         d[j] = win[(wd0_n + j) * LZ_BLOCK];
+#pragma unroll
+      for (uint32_t j = 0; j < 38; j++)
+        DG_MATERIALISE(d[j]); // all 19 reads in flight together: left alone, hipcc issues them one at a time between the compares
       const uint32_t U0 = lz_alignbyte(d[33], d[32], s), U1 = lz_alignbyte(d[34], d[33], s), U2 = lz_alignbyte(d[35], d[34], s),
                      U3 = lz_alignbyte(d[36], d[35], s);
       const uint32_t A0 = (U0 & 0xFFu) * 0x01010101u, A1 = ((U0 >> 8) & 0xFFu) * 0x01010101u, A2 = ((U0 >> 16) & 0xFFu) * 0x01010101u;
@@ -346,7 +350,7 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
 #pragma unroll
       for (uint32_t j = 0; j < 33; j++)
       {
-        const uint32_t y = (d[j] ^ A0) | (lz_alignbyte(d[j + 1], d[j], 1) ^ A1) | (lz_alignbyte(d[j + 1], d[j], 2) ^ A2);
+        const uint32_t y = xor_then_or(lz_alignbyte(d[j + 1], d[j], 2), A2, xor_then_or(lz_alignbyte(d[j + 1], d[j], 1), A1, d[j] ^ A0));
         cn[j >> 3] = lz_shift_in_nibble(cn[j >> 3], lz_gather_flags(lz_zero_bytes_approx(y)));
       }
       cn[4] >>= 28;
