@@ -93,6 +93,18 @@ DG_DEV uint32_t andn_and(uint32_t a, uint32_t b, uint32_t c) // ~a & b & c
 #endif
 }
 
+// Index of the lowest set bit; all ones for x == 0 (what v_ffbl_b32 does by itself: __builtin_ctz adds a compare and a select)
+DG_DEV uint32_t lowest_bit_or_ones(uint32_t x)
+{
+#if defined(DEGA_SIM)
+  return x != 0 ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu;
+#else
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#endif
+}
+
 // Number of leading one bits of x, for x with bit 31 set and not all ones (v_ffbh_i32 counts the bits equal to the sign).
 DG_DEV uint32_t leading_ones(uint32_t x)
 {

@@ -46,7 +46,10 @@ constexpr uint32_t LZ_WIN_DW = 108;              // window dwords per lane (432 
 constexpr uint32_t LZ_WIN_BYTES = 4 * LZ_WIN_DW;
 // a freshly loaded window (history, up to 15 bytes of alignment) must hold the longest match, or a step could never end
 static_assert(LZ_WIN_BYTES >= LZ_HISTORY + 15 + LZ_MAX_LENGTH && LZ_WIN_DW % 4 == 0, "window too small");
-constexpr uint32_t LZ_POP = 5;                   // candidates of one mask register handled per pass
+#ifndef DG_LZ_POP
+#define DG_LZ_POP 5
+#endif
+constexpr uint32_t LZ_POP = DG_LZ_POP;           // candidates of one mask register handled per pass (tools/tunebench.py)
 constexpr uint32_t LZ_AHEAD = 48;                // look-ahead a step needs in the window: 24 bytes in registers + slack
 constexpr uint32_t LZ_SYM_DW = LZ_LIST / 4, LZ_CNT_DW = LZ_LIST / 2, LZ_STAGE_DW = 4;
 constexpr uint32_t LZ_OFF_WIN = 0, LZ_OFF_SYM = LZ_OFF_WIN + LZ_WIN_DW * LZ_BLOCK, LZ_OFF_CNT = LZ_OFF_SYM + LZ_SYM_DW * LZ_BLOCK,
@@ -124,11 +127,11 @@ DG_DEV uint32_t lz_common16(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, 
 // the same for 8-byte strings (2 dwords), 0..8
 DG_DEV uint32_t lz_common8(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1)
 {
+  // the lowest differing bit of the 64: v_ffbl_b32 gives all ones for a zero word, so no selects are needed
   const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1;
-  uint32_t r = 8u;
-  r = x1 != 0 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : r;
-  r = x0 != 0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : r;
-  return r;
+  const uint32_t f0 = lowest_bit_or_ones(x0), f1 = lowest_bit_or_ones(x1) | 32u;
+  const uint32_t f = f0 < f1 ? f0 : f1;
+  return (f < 64u ? f : 64u) >> 3;
 }
 
 // the static prefix code of list position p < 19 (lzmh.c:86-106): returns the code, its length in len
@@ -270,9 +273,9 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
   bool search = false;
   DG_STAMP_DECL;
 
+  uint32_t peer = peer_load(pub_peer); // one pass old when it is used (the coder's count only grows: the room test errs on the safe side)
   for (;;)
   {
-    const uint32_t peer = peer_load(pub_peer);
     stop = stop || (peer & LZ_PUB_FINAL) != 0u;
     const bool todo = P < n_eff && !stop;
     if (!wave_any(todo))
@@ -281,9 +284,11 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
     if (!wave_any(start || (todo && verifying)))
     {
       wave_sleep<DG_LZ_SEARCH_SLEEP>();
+      peer = peer_load(pub_peer);
       continue;
     }
     DG_STAMP(7);
+    peer = peer_load(pub_peer); // for the next pass: comes back together with this pass's window reads
 
     // ---- window: when a lane that begins a step needs it, every lane with work reloads [P-128 (rounded down to 16), +432).
     //      A lane in the middle of a step takes part as well -- its candidates all lie in the last 132 bytes before P,
@@ -393,10 +398,17 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
       const bool go = verifying && best < lim;
       // the nearest mask register that still has candidates, and the next one: a lane whose nearest register holds fewer
       // than LZ_POP goes on in the next (still nearest first), so that a step's few candidates rarely need a second pass
-      const uint32_t r32 = cm[4] != 0u ? 128u : cm[3] != 0u ? 96u : cm[2] != 0u ? 64u : cm[1] != 0u ? 32u : 0u; // 32 * the register
-      uint32_t m = cm[4] != 0u ? cm[4] : cm[3] != 0u ? cm[3] : cm[2] != 0u ? cm[2] : cm[1] != 0u ? cm[1] : cm[0];
-      const uint32_t s32 = (r32 > 96u && cm[3] != 0u) ? 96u : (r32 > 64u && cm[2] != 0u) ? 64u : (r32 > 32u && cm[1] != 0u) ? 32u : 0u;
-      uint32_t m2 = r32 == 0u ? 0u : (s32 == 96u ? cm[3] : s32 == 64u ? cm[2] : s32 == 32u ? cm[1] : cm[0]);
+      // (one upward sweep with selects: the nested conditions of the obvious form came out as masked branches)
+      uint32_t r32 = 0u, s32 = 0u, m = cm[0], m2 = 0u; // r32, s32: 32 * the register
+#pragma unroll
+      for (uint32_t k = 1; k < 5; k++)
+      {
+        const bool nz = cm[k] != 0u;
+        m2 = nz ? m : m2;
+        s32 = nz ? r32 : s32;
+        m = nz ? cm[k] : m;
+        r32 = nz ? 32u * k : r32;
+      }
       m = go ? m : 0u;
       m2 = go ? m2 : 0u;
       uint32_t qb[LZ_POP], e[LZ_POP][3];
