@@ -18,8 +18,8 @@
 //            per dword 2 v_alignbyte, xor, two v_bitop3, a zero-byte test (add, v_bitop3) and a multiply that gathers the
 //            four flags -- 9
 //            (round 2: 11) instructions for 4 positions instead of a loop iteration with two dependent LDS reads per offset.
-//   phase 2  candidates are popped nearest first (= ascending offset), five of a mask register per pass of the wave's
-//            loop, and measured against the input bytes held in registers -- the first 8 bytes of all five, then the
+//   phase 2  candidates are popped nearest first (= ascending offset), six per pass of the wave's
+//            loop, and measured against the input bytes held in registers -- the first 8 bytes of all six, then the
 //            next 8 of the few that match those (all LDS reads of a round in flight together); `len > best` in that
 //            order keeps the nearest of equals.  A lane with more candidates keeps its step and takes further passes
 //            while the other lanes go on to their next steps.
@@ -47,7 +47,7 @@ constexpr uint32_t LZ_WIN_BYTES = 4 * LZ_WIN_DW;
 // a freshly loaded window (history, up to 15 bytes of alignment) must hold the longest match, or a step could never end
 static_assert(LZ_WIN_BYTES >= LZ_HISTORY + 15 + LZ_MAX_LENGTH && LZ_WIN_DW % 4 == 0, "window too small");
 #ifndef DG_LZ_POP
-#define DG_LZ_POP 5
+#define DG_LZ_POP 6 // (on the probe batch: 4 and 5 cost 1.6 % more, 8 costs 8 % more)
 #endif
 constexpr uint32_t LZ_POP = DG_LZ_POP;           // candidates of one mask register handled per pass (tools/tunebench.py)
 constexpr uint32_t LZ_AHEAD = 48;                // look-ahead a step needs in the window: 24 bytes in registers + slack
@@ -260,7 +260,7 @@ DG_DEV void lzmh_searching_wave(const LzmhEncodeArgs &a, uint32_t *lds, uint32_t
   uint32_t wr = 0;         // tokens handed over
   bool reload = true;
   bool stop = false;       // the coder wants no more of this channel
-  // A step in the making: the candidates of a step are measured five per pass of the wave's loop, and a lane whose step
+  // A step in the making: the candidates of a step are measured six per pass of the wave's loop, and a lane whose step
   // has more of them (a line start of the ASCII workload has 16, the average step 2) simply takes more passes -- the
   // other lanes go on to their next steps meanwhile.  (In one lockstep step per lane the wave measured 25 candidates
   // per step for an average lane that has 2.)
