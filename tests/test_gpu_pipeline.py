@@ -183,6 +183,35 @@ def test_rows_uploaded_in_bands_beside_the_running_kernel(dca, ctx, monkeypatch)
     assert (ef == 0).all() and (bf == bg).all() and pf.tobytes() == pg.tobytes()
 
 
+def test_pinned_samples_read_in_place_by_the_kernel(dca, ctx, monkeypatch):
+    """A chunk that is all columns of the caller's pinned array is not uploaded: the encode kernel's filling waves fetch
+    the rows from host memory themselves.  Same streams as through the copy engine (DEGA_PIPELINE_IN_PLACE=0) and as
+    the oracle's; a channel whose stream outgrows its samples takes the worst-case pass from the same rows; float rows."""
+    rng = np.random.default_rng(77)
+    for Cn, T in ((257, 4500), (64, 131), (1000, 33)):
+        x = walk(rng, T, Cn)
+        if T > 1000:
+            x[:, 5] = rng.integers(0, 1 << 30, T)  # noise: its stream is longer than its samples
+        pin = dca.PinnedArray((T, Cn), np.int32)
+        pin.array[:] = x
+        monkeypatch.setenv("DEGA_PIPELINE_IN_PLACE", "1")
+        p1, o1, b1, e1 = ctx.encode_job(pin.array, adaptive=1)
+        monkeypatch.setenv("DEGA_PIPELINE_IN_PLACE", "0")
+        p0, o0, b0, e0 = ctx.encode_job(pin.array, adaptive=1)
+        assert (e1 == 0).all() and (e0 == 0).all() and (b1 == b0).all() and (o1 == o0).all() and p1.tobytes() == p0.tobytes(), (Cn, T)
+        for c in (0, 5, Cn - 1):
+            ret, b, n = orc.encode_i32(np.ascontiguousarray(x[:, c]), 1)
+            assert ret == 0 and int(b1[c]) == n and stream_of(p1, o1, c) == b, (Cn, T, c)
+    v = (np.cumsum(rng.normal(0, 0.4, (5000, 130)), axis=0) + 230.0).astype(np.float32)
+    pf = dca.PinnedArray(v.shape, np.float32)
+    pf.array[:] = v
+    monkeypatch.setenv("DEGA_PIPELINE_IN_PLACE", "1")
+    a = ctx.encode_job(pf.array, adaptive=1, samples=dca.SAMPLES_F32, factor=100.0)
+    monkeypatch.setenv("DEGA_PIPELINE_IN_PLACE", "0")
+    b = ctx.encode_job(v, adaptive=1, samples=dca.SAMPLES_F32, factor=100.0)
+    assert (a[3] == 0).all() and (a[2] == b[2]).all() and a[0].tobytes() == b[0].tobytes()
+
+
 def test_streams_longer_than_their_samples_take_the_worst_case_pass(dca, ctx):
     """Noise: ~60 coded bits per 32-bit sample.  The pipeline's first attempt sizes slabs for streams no longer than their
     samples; chunks that do not fit are redone with worst-case slabs -- same streams as the oracle's, mixed with channels
