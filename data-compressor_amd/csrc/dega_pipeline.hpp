@@ -639,6 +639,14 @@ static int encode_redo_chunk(dega_hip_ctx *ctx, Pipeline *pl, Slot &sl, const Sh
   return DEGA_OK;
 }
 
+// DEGA_PIPELINE_AHEAD=n: chunks whose first stage is enqueued before the oldest one's second stage (default 2; measurement)
+static size_t stages_ahead()
+{
+  const char *e = getenv("DEGA_PIPELINE_AHEAD");
+  const long v = e != nullptr ? atol(e) : 2;
+  return (size_t)(v < 1 ? 1 : v);
+}
+
 // Pinned samples are read by the encode kernel where they lie (DEGA_PIPELINE_IN_PLACE=0: through the copy engine instead)
 static bool read_in_place()
 {
@@ -839,9 +847,16 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
   };
 
   // chunk k + nslots reuses the slot of chunk k: its second stage has to be enqueued first
-  for (size_t k = 0; k < plan.nchunks + (size_t)plan.nslots; k++)
+  // How far the first stages run ahead of the second ones.  Not as far as the slots would allow: HIP puts the streams
+  // on a few hardware queues, and a queue takes its packets in order -- with all eight chunks' first stages enqueued up
+  // front, chunk 0's gather and download (enqueued when its sizes were on the host, 7 ms into the call) sat behind the
+  // launches of a later chunk that were still waiting for their bands, and went out at 46 ms; every chunk's streams
+  // came home after the last upload (trace of 65 536 x 10 800, gpurun_out/e2eprof; 66 ms a call).  Two chunks ahead
+  // keep the link busy (enqueueing a chunk takes 0.15 ms) and a download waits for one chunk's launches at most.
+  const size_t ahead = std::min<size_t>((size_t)plan.nslots, stages_ahead());
+  for (size_t k = 0; k < plan.nchunks + ahead; k++)
   {
-    if (k >= (size_t)plan.nslots && (ret = stage2(k - (size_t)plan.nslots)) != DEGA_OK)
+    if (k >= ahead && (ret = stage2(k - ahead)) != DEGA_OK)
       return ret;
     if (k < plan.nchunks && (ret = stage1(k)) != DEGA_OK)
       return ret;

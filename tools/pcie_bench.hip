@@ -92,6 +92,43 @@ int main(int argc, char **argv)
     CHECK(hipStreamSynchronize(s));
     printf("D2H pinned 2-D 32K/256K  %8.2f GB/s\n", width * rows / (now() - t0) / 1e9);
   }
+  // the same with wider pieces, with two and four 2-D copies side by side on their own streams (adjacent column ranges),
+  // and with the copy done by a kernel reading the pinned rows (what the encode kernel's filling waves would do)
+  {
+    const size_t pitch = 262144, rows = n / pitch;
+    for (size_t width : {(size_t)65536, (size_t)131072})
+    {
+      t0 = now();
+      CHECK(hipMemcpy2DAsync(dev, width, pinned, pitch, width, rows, hipMemcpyHostToDevice, s));
+      CHECK(hipStreamSynchronize(s));
+      printf("H2D pinned 2-D %3zuK/256K %8.2f GB/s\n", width >> 10, width * rows / (now() - t0) / 1e9);
+    }
+    hipStream_t ss[4];
+    for (auto &x : ss)
+      CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    for (int k : {2, 4})
+    {
+      const size_t width = 32768;
+      t0 = now();
+      for (int i = 0; i < k; i++)
+        CHECK(hipMemcpy2DAsync(dev + (size_t)i * width * rows, width, pinned + (size_t)i * width, pitch, width, rows, hipMemcpyHostToDevice, ss[i]));
+      for (int i = 0; i < k; i++)
+        CHECK(hipStreamSynchronize(ss[i]));
+      printf("H2D pinned 2-D 32K/256K x %d streams %8.2f GB/s in all\n", k, k * width * rows / (now() - t0) / 1e9);
+    }
+    // one chunk's rows cut into 4 row ranges on 4 streams (the same columns)
+    {
+      const size_t width = 32768, part = rows / 4;
+      t0 = now();
+      for (int i = 0; i < 4; i++)
+        CHECK(hipMemcpy2DAsync(dev + (size_t)i * part * width, width, pinned + (size_t)i * part * pitch, pitch, width, part, hipMemcpyHostToDevice, ss[i]));
+      for (int i = 0; i < 4; i++)
+        CHECK(hipStreamSynchronize(ss[i]));
+      printf("H2D pinned 2-D 32K/256K rows in 4 ranges on 4 streams %8.2f GB/s\n", 4 * part * width / (now() - t0) / 1e9);
+    }
+    for (auto &x : ss)
+      CHECK(hipStreamDestroy(x));
+  }
   // chunked pinned copies (64 MiB pieces)
   {
     const size_t piece = 64u << 20;
