@@ -395,6 +395,7 @@ constexpr int MAX_SLOTS = 16;
 struct Pipeline
 {
   Slot slot[MAX_SLOTS];
+  hipStream_t up = nullptr; // decode: the chunks' packed streams go up one after the other on this stream (each at the link's full rate)
   GrowDev redo_slabs, redo_packed, redo_meta;
   GrowPin redo_hmeta;
   Stager stager;
@@ -462,6 +463,8 @@ static void pipeline_destroy(Pipeline *p)
     sl.hmeta.release();
     sl.stage.release();
   }
+  if (p->up != nullptr)
+    (void)hipStreamDestroy(p->up);
   p->redo_slabs.release();
   p->redo_packed.release();
   p->redo_meta.release();
@@ -512,12 +515,12 @@ struct ChunkPlan
 
 // Chunks: enough of them to overlap copies and kernels (about 64 MiB of samples each, at most MAX_SLOTS at a time), whole
 // workgroups of channels, and -- when the batch does not fit the device beside its slabs -- as many slots as fit.
-static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes_per_channel_dev, int want_all_resident)
+static ChunkPlan plan_chunks(size_t C, size_t bytes_per_channel_in, size_t bytes_per_channel_dev, int want_all_resident, size_t most = 8)
 {
   ChunkPlan p;
   const size_t total = C * bytes_per_channel_in;
   size_t n = total / ((size_t)64 << 20);
-  n = std::max<size_t>(1, std::min<size_t>(n, 8));
+  n = std::max<size_t>(1, std::min<size_t>(n, most));
   if (getenv("DEGA_PIPELINE_CHUNKS") != nullptr) // measurement knob
     n = std::max(1, atoi(getenv("DEGA_PIPELINE_CHUNKS")));
   if (C <= 512)
@@ -644,6 +647,18 @@ static size_t stages_ahead()
 {
   const char *e = getenv("DEGA_PIPELINE_AHEAD");
   const long v = e != nullptr ? atol(e) : 2;
+  return (size_t)(v < 1 ? 1 : v);
+}
+
+static bool decode_uploads_first() // DEGA_PIPELINE_UPLOADS_FIRST=0: upload and kernel enqueued chunk by chunk (measurement)
+{
+  const char *e = getenv("DEGA_PIPELINE_UPLOADS_FIRST");
+  return e == nullptr || atoi(e) != 0;
+}
+static size_t decode_stages_ahead() // DEGA_PIPELINE_AHEAD_DECODE=n: the same for a decode call (default: as far as the slots allow)
+{
+  const char *e = getenv("DEGA_PIPELINE_AHEAD_DECODE");
+  const long v = e != nullptr ? atol(e) : MAX_SLOTS;
   return (size_t)(v < 1 ? 1 : v);
 }
 
@@ -915,17 +930,24 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
   for (size_t c = 0; c < j.C; c++)
     longest_all = std::max<uint64_t>(longest_all, offsets[c + 1] - offsets[c]);
   const size_t dev_per_channel = j.T * osz + (size_t)(span / std::max<size_t>(j.C, 1)) + (size_t)longest_all + 64;
-  const ChunkPlan plan = plan_chunks(j.C, j.T * osz, dev_per_channel, 0);
+  // At most four chunks: a decode kernel takes its channels' serial time however few they are, the hardware queues run
+  // few of them side by side, and the rows go home in bands beside the running kernel anyway (65 536 x 10 800 from
+  // pinned memory: 8 chunks 83 ms, 4: 63 ms, 2: 66.5 ms, 1: 66 ms).
+  const ChunkPlan plan = plan_chunks(j.C, j.T * osz, dev_per_channel, 0, 4);
   struct DecChunk
   {
     size_t c0, n;
     int slot;
     size_t band_rows; // 0: the samples come home after the kernel; else in bands of rows beside it
+    size_t cap;       // slab bytes per channel
   };
   std::vector<DecChunk> chunks(plan.nchunks);
   const bool samples_pinned = is_pinned(samples), packed_pinned = is_pinned(packed);
 
-  auto stage1 = [&](size_t k) -> int {
+  // (the slot's stream is idle when stage1a runs -- it synchronises it -- so nothing of the slot's is still in use)
+  const bool one_upload_stream = packed_pinned && decode_uploads_first();
+  // first stage, part a: the chunk's packed streams go up and are spread into slabs
+  auto stage1a = [&](size_t k) -> int {
     DecChunk &ch = chunks[k];
     ch.c0 = k * plan.chunk_channels;
     ch.n = std::min(plan.chunk_channels, j.C - ch.c0);
@@ -940,6 +962,7 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
     for (size_t i = 0; i < ch.n; i++)
       longest = std::max<uint64_t>(longest, offsets[ch.c0 + i + 1] - offsets[ch.c0 + i]);
     const size_t cap = ((size_t)longest + 16 + 3) & ~(size_t)3; // room for the decoder's word look-ahead
+    ch.cap = cap;
     HIP_TRY(ctx, sl.a.need((size_t)nbytes + 64), DEGA_ERROR_MEMORY);
     HIP_TRY(ctx, sl.b.need(ch.n * cap + 64), DEGA_ERROR_MEMORY);
     HIP_TRY(ctx, sl.c.need(ch.n * j.T * osz + 64), DEGA_ERROR_MEMORY);
@@ -952,13 +975,39 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
       hm.offsets[i] = offsets[ch.c0 + i] - o0;
     }
     hm.offsets[ch.n] = nbytes;
-    HIP_TRY(ctx, hipMemcpyAsync(sl.meta.p, sl.hmeta.p, (2 * ch.n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, sl.s), DEGA_ERROR_LIBRARY_CALL);
-    HIP_TRY(ctx, rows_to_device(pl, sl.s, sl.a.p, packed + o0, (size_t)nbytes, (size_t)nbytes, 1, packed_pinned), DEGA_ERROR_LIBRARY_CALL);
+    // The uploads of all chunks share ONE stream: side by side on their own streams they share the link, every one of
+    // them takes as long as all together, and the first kernel starts when the last upload is done (two chunks: 74 ms a
+    // call where one chunk takes 66).  The chunk's own stream goes on behind the upload's event.
+    hipStream_t us = sl.s;
+    if (one_upload_stream)
+    {
+      if (pl->up == nullptr)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&pl->up, hipStreamNonBlocking), DEGA_ERROR_LIBRARY_CALL);
+      if (sl.reuse_ev == nullptr)
+        HIP_TRY(ctx, hipEventCreateWithFlags(&sl.reuse_ev, hipEventDisableTiming), DEGA_ERROR_LIBRARY_CALL);
+      us = pl->up;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(sl.meta.p, sl.hmeta.p, (2 * ch.n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, us), DEGA_ERROR_LIBRARY_CALL);
+    HIP_TRY(ctx, rows_to_device(pl, us, sl.a.p, packed + o0, (size_t)nbytes, (size_t)nbytes, 1, packed_pinned), DEGA_ERROR_LIBRARY_CALL);
     {
       GatherArgs g{(const uint8_t *)sl.b.p, cap, dm.offsets, ch.n, (uint8_t *)sl.a.p};
-      hipLaunchKernelGGL(dega_scatter_kernel, dim3((unsigned)((ch.n + WAVES - 1) / WAVES)), dim3(BLOCK), 0, sl.s, g);
+      hipLaunchKernelGGL(dega_scatter_kernel, dim3((unsigned)((ch.n + WAVES - 1) / WAVES)), dim3(BLOCK), 0, us, g);
       HIP_TRY(ctx, hipGetLastError(), DEGA_ERROR_LIBRARY_CALL);
     }
+    if (us != sl.s)
+    {
+      HIP_TRY(ctx, hipEventRecord(sl.reuse_ev, us), DEGA_ERROR_LIBRARY_CALL);
+      HIP_TRY(ctx, hipStreamWaitEvent(sl.s, sl.reuse_ev, 0), DEGA_ERROR_LIBRARY_CALL);
+    }
+    return DEGA_OK;
+  };
+  // first stage, part b: the decode kernel
+  auto stage1b = [&](size_t k) -> int {
+    DecChunk &ch = chunks[k];
+    Slot &sl = pl->slot[ch.slot];
+    const size_t cap = ch.cap;
+    MetaView hm(sl.hmeta.p, ch.n), dm(sl.meta.p, ch.n);
+    int r;
     Shape cj = j;
     cj.C = ch.n;
     cj.ld = ch.n;
@@ -1027,11 +1076,29 @@ static int decode_share(dega_hip_ctx *ctx, const Shape &j, const uint8_t *packed
         out_count[ch.c0 + i] = hm.counts[i];
     return DEGA_OK;
   };
-  for (size_t k = 0; k < plan.nchunks + (size_t)plan.nslots; k++)
+  if ((size_t)plan.nslots >= plan.nchunks && decode_uploads_first())
   {
-    if (k >= (size_t)plan.nslots && (ret = stage2(k - (size_t)plan.nslots)) != DEGA_OK)
+    // Every chunk has a slot of its own: all the uploads are enqueued before the first decode kernel.  HIP puts the
+    // streams on a few hardware queues that take their packets in order; with upload and kernel enqueued chunk by chunk,
+    // the upload of chunk 4 sat behind the 8 ms kernel of chunk 0 on their queue, chunks 6 and 7 behind that of chunk 4,
+    // and the link stood idle for 20 ms of an 80 ms call (trace of 65 536 x 10 800, gpurun_out/e2eprof_dec).
+    for (size_t k = 0; k < plan.nchunks; k++)
+      if ((ret = stage1a(k)) != DEGA_OK)
+        return ret;
+    for (size_t k = 0; k < plan.nchunks; k++)
+      if ((ret = stage1b(k)) != DEGA_OK)
+        return ret;
+    for (size_t k = 0; k < plan.nchunks; k++)
+      if ((ret = stage2(k)) != DEGA_OK)
+        return ret;
+    return DEGA_OK;
+  }
+  const size_t ahead = std::min<size_t>((size_t)plan.nslots, decode_stages_ahead());
+  for (size_t k = 0; k < plan.nchunks + ahead; k++)
+  {
+    if (k >= ahead && (ret = stage2(k - ahead)) != DEGA_OK)
       return ret;
-    if (k < plan.nchunks && (ret = stage1(k)) != DEGA_OK)
+    if (k < plan.nchunks && ((ret = stage1a(k)) != DEGA_OK || (ret = stage1b(k)) != DEGA_OK))
       return ret;
   }
   return DEGA_OK;
