@@ -7,3 +7,4 @@ rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $O/s
 ls $O/stats/*/
 cat $O/stats/*/*kernel_stats.csv | head -8
 cat $O/stats/*/*memory_copy_stats.csv 2>/dev/null | head -8
+python3 $R/tools/e2e_trace_summary.py $O/stats/*/
