@@ -150,6 +150,37 @@ def test_pipeline_chunks_and_streams_equal_device_resident(dca, ctx):
     assert ret == dca.ERROR_MEMORY and int(o2[Cn]) == packed.size and (b2 == hbits).all() and (e2 == 0).all()
 
 
+def test_order_of_the_enqueues_does_not_change_the_result(dca, ctx, monkeypatch):
+    """How far the first stages of an encode call run ahead of the second ones (DEGA_PIPELINE_AHEAD), whether a decode
+    call's uploads go first on one stream (DEGA_PIPELINE_UPLOADS_FIRST) and how many chunks there are only change WHEN the
+    copies and kernels run: same packed streams, same samples back.  Pinned and pageable memory, a ragged last chunk."""
+    import torch
+    Cn, T = 2600, 4200
+    x = ctx.synth(Cn, T, seed=5, S=80)
+    out, bits, err = ctx.encode(x, adaptive=1, cap=4 * T + 64)
+    dpacked, doff = ctx.compact(out, bits)
+    torch.cuda.synchronize()
+    want = dpacked.cpu().numpy().tobytes()
+    xh = x.cpu().numpy()
+    pin = dca.PinnedArray((T, Cn), np.int32)
+    pin.array[:] = xh
+    for chunks, ahead, first in (("5", "1", "1"), ("5", "2", "0"), ("5", "16", "1"), ("3", "2", "1"), ("1", "2", "1")):
+        monkeypatch.setenv("DEGA_PIPELINE_CHUNKS", chunks)
+        monkeypatch.setenv("DEGA_PIPELINE_AHEAD", ahead)
+        monkeypatch.setenv("DEGA_PIPELINE_AHEAD_DECODE", ahead)
+        monkeypatch.setenv("DEGA_PIPELINE_UPLOADS_FIRST", first)
+        for src in (xh, pin.array):
+            packed, offsets, hbits, herr = ctx.encode_job(src, adaptive=1)
+            assert (herr == 0).all() and (offsets.astype(np.int64) == doff.cpu().numpy()).all() and packed.tobytes() == want, (chunks, ahead, first)
+        pk = dca.PinnedArray((packed.size,), np.uint8)
+        pk.array[:] = packed
+        back, derr = ctx.decode_job(packed, offsets, hbits, T, adaptive=1)
+        assert (derr == 0).all() and (back == xh).all(), (chunks, ahead, first)
+        pin2 = dca.PinnedArray((T, Cn), np.int32)
+        back2, derr2 = ctx.decode_job(pk.array, offsets, hbits, T, adaptive=1, out=pin2.array)
+        assert (derr2 == 0).all() and (pin2.array == xh).all(), (chunks, ahead, first)
+
+
 def test_rows_uploaded_in_bands_beside_the_running_kernel(dca, ctx, monkeypatch):
     """Few, long channels: the encode kernel starts before the samples are there and takes the rows as the bands of the
     upload arrive (EncodeArgs::rows_ready); the decode kernel's rows go home in bands while it is still running
