@@ -726,7 +726,7 @@ static int encode_share(dega_hip_ctx *ctx, const Shape &j, const void *samples, 
       // from it themselves (LDS-DMA over the link, 256-byte row segments: 8 192 x 86 400 in 65.2 ms against 66.5 ms
       // with bands through the copy engine) -- no image of the samples on the device, one launch.  Only for whole
       // rows: a chunk of the columns of a wider array is read at 32 - 36 GB/s this way (rows 256 KiB apart: a
-      // translation per row), where the copy engine's pitched copies reach 45 GB/s.
+      // translation per row), where the copy engine runs at the link's rate (56.8 GB/s, tools/pcie_bench).
       ch.rows = (const uint8_t *)dev_src;
       ch.rows_ld = j.ld;
       cj.ld = j.ld;
